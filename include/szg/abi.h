@@ -1,0 +1,428 @@
+/*
+ * szg/abi.h — data ABI + C entry points of the MI355X-native deferred-shading +
+ * Hillaire-atmosphere path.
+ *
+ * This header is the drop-in boundary. Everything here is plain C: PODs, device
+ * pointers, sizes, int status codes. No HIP, torch or C++ types cross it
+ * (`void* stream` is a hipStream_t; NULL = the default stream).
+ *
+ * Every item cites the reference interface it replaces, as
+ * `path:line` relative to the reference checkout (syzygy/source/syzygy/... or
+ * shaders/...).
+ *
+ * Conventions (reference geometryhelpers.hpp:16-29, skyview_LUT.comp:106-112):
+ *   engine/world space : +x right, +y DOWN, +z forward, metres
+ *   atmosphere space   : +y UP, megametres, origin at the planet centre
+ *   matrices           : column-major, M*v
+ *   all arithmetic     : fp32
+ */
+#ifndef SZG_ABI_H
+#define SZG_ABI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SZG_ABI_VERSION 1
+
+/* ------------------------------------------------------------------------- */
+/* Status codes (reference: construction returns optional/nullptr + log,      */
+/* record* never fail — deferred.cpp:153-163, skyview.cpp:713-740).           */
+/* ------------------------------------------------------------------------- */
+#define SZG_OK 0
+#define SZG_ERR_INVALID_ARGUMENT (-1)
+#define SZG_ERR_NO_DEVICE (-2)
+#define SZG_ERR_OUT_OF_MEMORY (-3)
+#define SZG_ERR_HIP (-4)
+#define SZG_ERR_CAPACITY (-5)
+
+/* ------------------------------------------------------------------------- */
+/* Packed parameter blocks — byte-identical to renderer/gputypes.hpp:17-126   */
+/* (std430 mirrors of shaders/types/{camera.glsl,atmosphere.glinl,lights.glsl}) */
+/* ------------------------------------------------------------------------- */
+typedef struct szg_mat4
+{
+    float m[16]; /* column-major: m[col*4 + row] */
+} szg_mat4;
+
+/* gputypes.hpp:17-36, shaders/types/camera.glsl:1-18 */
+typedef struct szg_camera_packed
+{
+    szg_mat4 projection;
+    szg_mat4 inverseProjection;
+    szg_mat4 view;
+    szg_mat4 viewInverseTranspose;
+    szg_mat4 rotation;
+    szg_mat4 projViewInverse;
+    float forwardWorld[4];
+    float position[4];
+} szg_camera_packed;
+
+/* gputypes.hpp:39-72, shaders/types/atmosphere.glinl:3-32 */
+typedef struct szg_atmosphere_packed
+{
+    float scatteringRayleighPerMm[3];
+    float densityScaleRayleighMm;
+    float absorptionRayleighPerMm[3];
+    float planetRadiusMm;
+    float scatteringMiePerMm[3];
+    float densityScaleMieMm;
+    float absorptionMiePerMm[3];
+    float atmosphereRadiusMm;
+    float incidentDirectionSun[3]; /* atmosphere space, direction light travels */
+    uint32_t padding0;
+    float scatteringOzonePerMm[3];
+    uint32_t padding1;
+    float absorptionOzonePerMm[3];
+    uint32_t padding2;
+    float sunIntensitySpectrum[3];
+    float sunAngularRadius;
+} szg_atmosphere_packed;
+
+/* gputypes.hpp:74-90, shaders/types/lights.glsl:1-12 */
+typedef struct szg_directional_light_packed
+{
+    float color[4];
+    float forward[4];
+    szg_mat4 projection;
+    szg_mat4 view;
+    float strength;
+    uint32_t padding0[3];
+} szg_directional_light_packed;
+
+/* gputypes.hpp:92-115, shaders/types/lights.glsl:14-29 */
+typedef struct szg_spot_light_packed
+{
+    float color[4];
+    float forward[4];
+    szg_mat4 projection;
+    szg_mat4 view;
+    float position[4];
+    float strength;
+    float falloffFactor;
+    float falloffDistance;
+    uint32_t padding0;
+} szg_spot_light_packed;
+
+/* ------------------------------------------------------------------------- */
+/* Push-constant blocks, kept byte-identical so a caller that already fills    */
+/* the reference's structs can hand them over unchanged. Device addresses are  */
+/* plain 64-bit HIP device pointers.                                           */
+/* ------------------------------------------------------------------------- */
+/* skyview.hpp:64-72 (transmittance_LUT.comp:15-20), 16 B */
+typedef struct szg_pc_transmittance
+{
+    uint64_t atmosphereBuffer;
+    uint32_t atmosphereIndex;
+    uint32_t padding;
+} szg_pc_transmittance;
+
+/* skyview.hpp:89-96 (skyview_LUT.comp:22-29), GLSL block size 32 B */
+typedef struct szg_pc_skyview
+{
+    uint64_t atmosphereBuffer;
+    uint64_t cameraBuffer;
+    uint32_t atmosphereIndex;
+    uint32_t cameraIndex;
+    uint32_t padding[2];
+} szg_pc_skyview;
+
+/* skyview.hpp:125-144 (camera.comp:50-67), 64 B */
+typedef struct szg_pc_composite
+{
+    uint64_t atmosphereBuffer;
+    uint64_t cameraBuffer;
+    uint32_t atmosphereIndex;
+    uint32_t cameraIndex;
+    uint32_t drawExtent[2];
+    uint32_t sunShadowMapIndex;
+    uint32_t padding0;
+    uint32_t gbufferExtent[2];
+    uint64_t directionalLights;
+    uint32_t sunLightIndex;
+    uint32_t padding1;
+} szg_pc_composite;
+
+/* deferred.hpp:82-98 (lights.comp:41-57), 64 B */
+typedef struct szg_pc_lights
+{
+    uint64_t cameraBuffer;
+    uint32_t padding0;
+    uint32_t padding1;
+    uint64_t directionalLightsBuffer;
+    uint64_t spotLightsBuffer;
+    uint32_t directionalLightCount;
+    uint32_t spotLightCount;
+    uint32_t directionalLightSkipCount;
+    uint32_t cameraIndex;
+    float gbufferOffset[2];
+    float gbufferExtent[2];
+} szg_pc_lights;
+
+/* ------------------------------------------------------------------------- */
+/* Images: Vulkan optimal-tiled images become linear row-major device buffers */
+/* with an explicit pitch. Formats from gbuffer.cpp:27-40, skyview.cpp:78-88,  */
+/* 175-185, editor/uilayer.cpp:285-308, shadowpass.cpp:22-60.                  */
+/* ------------------------------------------------------------------------- */
+typedef enum szg_format
+{
+    SZG_FORMAT_UNDEFINED = 0,
+    SZG_FORMAT_RGBA16_SFLOAT = 1, /* 8 B/texel  : G-buffer diffuse/specular/normal/ORM */
+    SZG_FORMAT_RGBA32_SFLOAT = 2, /* 16 B/texel : G-buffer worldPosition, both LUTs, debug colour */
+    SZG_FORMAT_RGBA16_UNORM = 3,  /* 8 B/texel  : scene colour */
+    SZG_FORMAT_D32_SFLOAT = 4     /* 4 B/texel  : scene depth, shadow maps (reverse-Z, 0 = far) */
+} szg_format;
+
+typedef struct szg_image
+{
+    void* data;           /* device pointer; NULL = absent */
+    uint32_t width;       /* ALLOCATED extent in texels (imageSize() of the reference) */
+    uint32_t height;
+    uint32_t pitch_bytes; /* row pitch, >= width * texel size */
+    uint32_t format;      /* szg_format */
+} szg_image;
+
+/* VkRect2D of the reference API. The reference ignores the offset (lights.comp
+ * gbufferOffset is always 0: deferred.cpp:764; camera.comp has none), so do we. */
+typedef struct szg_rect
+{
+    int32_t x, y;
+    uint32_t width, height;
+} szg_rect;
+
+/* renderer/gbuffer.hpp:17-48: five separate planes, NEAREST clamp-to-edge. */
+typedef struct szg_gbuffer
+{
+    szg_image diffuse;       /* RGBA16F, a = 1 geometry / 0 background (offscreen.frag:71) */
+    szg_image specular;      /* RGBA16F */
+    szg_image normal;        /* RGBA16F, w = 0 */
+    szg_image worldPosition; /* RGBA32F, w = 1 */
+    szg_image occlusionRoughnessMetallic; /* RGBA16F */
+} szg_gbuffer;
+
+/* renderer/scenetexture.hpp:11-81: colour + depth render target. `debug_color`
+ * has no reference counterpart: when non-NULL each pass also writes its
+ * pre-quantisation fp32 RGBA result there, for parity tests. */
+typedef struct szg_scene_texture
+{
+    szg_image color;       /* RGBA16_UNORM */
+    szg_image depth;       /* D32_SFLOAT, NEAREST clamp-to-border(0) */
+    szg_image debug_color; /* RGBA32_SFLOAT or data == NULL */
+} szg_scene_texture;
+
+/* renderer/shadowpass.hpp:33-93 (consumer side). maps[i].data == NULL means
+ * "no shadow map for this light": shadow factor 1.0, identical to sampling a
+ * cleared map (shadowmap.glinl:56). `maps` is a HOST array. */
+typedef struct szg_shadowmaps
+{
+    uint32_t count;
+    uint32_t padding;
+    const szg_image* maps;
+} szg_shadowmaps;
+
+/* Row tiling for multi-GPU (no reference counterpart). The frame's
+ * rows are cut into blocks of `block_rows`; block b belongs to rank b % nranks.
+ * A rank's images hold only its own rows, packed: local row l maps to global
+ * row ((l / block_rows) * nranks + rank) * block_rows + l % block_rows.
+ * nranks == 1 (or a NULL pointer) is the whole frame. */
+typedef struct szg_rowtile
+{
+    uint32_t block_rows;
+    uint32_t rank;
+    uint32_t nranks;
+    uint32_t local_rows; /* number of rows this rank holds */
+} szg_rowtile;
+
+/* ------------------------------------------------------------------------- */
+/* Synthetic geometry for the G-buffer fill (the rasteriser is   */
+/* replaced by an analytic ray-cast that reproduces the output conventions of  */
+/* deferred/offscreen.frag:61-79 and the raster state deferred.cpp:342-392).   */
+/* ------------------------------------------------------------------------- */
+typedef struct szg_fill_box
+{
+    float center[3];
+    float half_extent[3];
+    float metallic;
+    float roughness;
+} szg_fill_box;
+
+typedef struct szg_fill_scene
+{
+    float ground_y;           /* ground plane y (world, +y down), e.g. -1 (editor.cpp:541) */
+    float ground_half_extent; /* plane covers |x|,|z| <= this */
+    float checker_cell;       /* checkerboard cell in metres (assets.cpp:1343-1348 colours) */
+    float ground_roughness;   /* default 60/255 (assets.cpp:1311) */
+    uint32_t box_count;
+    uint32_t padding;
+    const szg_fill_box* boxes; /* HOST array */
+} szg_fill_scene;
+
+/* ------------------------------------------------------------------------- */
+/* Library                                                                     */
+/* ------------------------------------------------------------------------- */
+int szg_abi_version(void);
+/* Last error text of the calling thread ("" if none). */
+const char* szg_last_error(void);
+/* Number of visible HIP devices, or a negative status. */
+int szg_device_count(void);
+
+/* ------------------------------------------------------------------------- */
+/* SkyViewComputePipeline (renderer/pipelines/skyview.hpp:24-51)               */
+/* ------------------------------------------------------------------------- */
+typedef struct szg_skyview szg_skyview_t;
+
+typedef struct szg_skyview_desc
+{
+    uint32_t transmittance_width;  /* reference: 512 (skyview.cpp:78, common.glinl:13) */
+    uint32_t transmittance_height; /* reference: 128 */
+    uint32_t skyview_width;        /* reference: 2048 (skyview.cpp:175) */
+    uint32_t skyview_height;       /* reference: 1024 */
+    uint32_t flags;                /* SZG_SKYVIEW_* */
+    uint32_t padding;
+} szg_skyview_desc;
+
+/* Reuse LUTs of the previous record when atmosphere block / camera position are
+ * byte-identical (results identical; the reference recomputes every frame,
+ * skyview.cpp:799-893). Off by default. */
+#define SZG_SKYVIEW_CACHE_LUTS 1u
+
+/* skyview.hpp:36-37 `create(device, allocator)`; returns SZG_OK and *out, or a
+ * negative status and *out = NULL (reference: nullptr, skyview.cpp:713-740). */
+int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int device);
+/* skyview.hpp:27-34 destructor / destroy(). NULL is allowed. */
+void szg_skyview_destroy(szg_skyview_t* p);
+
+/* skyview.hpp:39-51 recordDrawCommands: transmittance LUT -> sky-view LUT ->
+ * camera composite, enqueued on `stream`, returns immediately
+ * (skyview.cpp:751-911). All `d_*` are device pointers to arrays of the packed
+ * structs (the reference's TStagedBuffer::deviceAddress()). */
+int szg_skyview_record_draw_commands(
+    szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture, szg_rect draw_rect,
+    const szg_rowtile* tile, const szg_gbuffer* gbuffer, const szg_shadowmaps* shadow_maps,
+    uint32_t atmosphere_index, const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+    const szg_camera_packed* d_cameras, uint32_t sun_light_index,
+    const szg_directional_light_packed* d_lights);
+
+/* The three dispatches of recordDrawCommands, individually (skyview.cpp:795-845,
+ * :847-893, :581-666). Tests and the bench time them separately. */
+int szg_skyview_record_transmittance(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                     const szg_atmosphere_packed* d_atmospheres);
+int szg_skyview_record_skyview_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                   const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                                   const szg_camera_packed* d_cameras);
+int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture,
+                                 szg_rect draw_rect, const szg_rowtile* tile, const szg_gbuffer* gbuffer,
+                                 const szg_shadowmaps* shadow_maps, uint32_t atmosphere_index,
+                                 const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                                 const szg_camera_packed* d_cameras, uint32_t sun_light_index,
+                                 const szg_directional_light_packed* d_lights);
+
+/* Accessors to the LUT images the pipeline owns (skyview.hpp:52-97 `map`). */
+int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out);
+int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out);
+
+/* ------------------------------------------------------------------------- */
+/* DeferredShadingPipeline (renderer/pipelines/deferred.hpp:23-119)            */
+/* ------------------------------------------------------------------------- */
+typedef struct szg_deferred szg_deferred_t;
+
+typedef struct szg_deferred_desc
+{
+    uint32_t capacity_width;  /* dimensionCapacity (deferred.hpp:31); reference 4096 (renderer.hpp:96) */
+    uint32_t capacity_height;
+    uint32_t max_spot_lights; /* reference 16 (deferred.cpp:166) */
+    uint32_t max_shadow_maps; /* reference 10 (deferred.cpp:179) */
+    uint32_t shadow_map_dim;  /* reference 8192 (deferred.cpp:180); 0 = allocate none */
+    uint32_t padding;
+} szg_deferred_desc;
+
+/* deferred.hpp:109-115 + shadowpass.hpp:24-28 */
+typedef struct szg_deferred_configuration
+{
+    float depthBiasConstant;
+    float depthBiasSlope;
+} szg_deferred_configuration;
+
+/* deferred.hpp:26-32 constructor. */
+int szg_deferred_create(szg_deferred_t** out, const szg_deferred_desc* desc, int device);
+/* deferred.hpp:49 cleanup(). NULL is allowed. */
+void szg_deferred_destroy(szg_deferred_t* p);
+
+/* deferred.hpp:34-44 recordDrawCommands (deferred.cpp:435-792): upload spot
+ * lights -> (shadow maps: inputs) -> G-buffer fill -> clear colour
+ * to opaque black -> lights dispatch. `h_spot_lights` is a HOST span exactly as
+ * in the reference (std::span<SpotLightPacked const>); `geometry` replaces
+ * std::span<MeshInstanced const>: NULL keeps the G-buffer contents the caller
+ * wrote through szg_deferred_gbuffer(). */
+int szg_deferred_record_draw_commands(
+    szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
+    const szg_scene_texture* scene_texture, uint32_t atmospheric_directional_lights_count,
+    const szg_directional_light_packed* d_directional_lights, uint32_t directional_light_count,
+    const szg_spot_light_packed* h_spot_lights, uint32_t spot_light_count, uint32_t view_camera_index,
+    const szg_camera_packed* d_cameras, const szg_fill_scene* geometry);
+
+/* The two device passes of recordDrawCommands, individually. */
+int szg_deferred_record_gbuffer_fill(szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
+                                     const szg_scene_texture* scene_texture, uint32_t view_camera_index,
+                                     const szg_camera_packed* d_cameras, const szg_fill_scene* geometry);
+int szg_deferred_record_lights(szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
+                               const szg_scene_texture* scene_texture,
+                               uint32_t atmospheric_directional_lights_count,
+                               const szg_directional_light_packed* d_directional_lights,
+                               uint32_t directional_light_count, const szg_spot_light_packed* h_spot_lights,
+                               uint32_t spot_light_count, uint32_t view_camera_index,
+                               const szg_camera_packed* d_cameras);
+
+/* deferred.hpp:46-47 gbuffer() / shadowMaps(). Pointers stay valid until destroy. */
+const szg_gbuffer* szg_deferred_gbuffer(szg_deferred_t* p);
+const szg_shadowmaps* szg_deferred_shadow_maps(szg_deferred_t* p);
+/* Attach/detach a caller-owned D32F shadow map for light slot `index` (slots
+ * run directional lights first, then spot lights: lights.comp:138-161).
+ * map == NULL or map->data == NULL detaches (shadow factor 1). */
+int szg_deferred_set_shadow_map(szg_deferred_t* p, uint32_t index, const szg_image* map);
+
+/* deferred.hpp:114-115 */
+int szg_deferred_get_configuration(const szg_deferred_t* p, szg_deferred_configuration* out);
+int szg_deferred_set_configuration(szg_deferred_t* p, const szg_deferred_configuration* cfg);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU composition (no reference counterpart; BASELINE north_star)       */
+/* ------------------------------------------------------------------------- */
+/* After a gather, rank 0 holds `nranks` packed row-tiles back to back in
+ * `gathered` (rank r at r * tile_pitch_bytes). Scatter their rows into the
+ * full-frame image `dst` following szg_rowtile's cyclic map. One HBM-bound
+ * copy kernel. */
+int szg_compose_rowtiles(void* stream, const void* gathered, size_t tile_stride_bytes, uint32_t nranks,
+                         uint32_t block_rows, const szg_image* dst, uint32_t width, uint32_t height);
+
+/* Number of local rows rank `rank` holds for a frame of `height` rows. */
+uint32_t szg_rowtile_local_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uint32_t nranks);
+
+/* ------------------------------------------------------------------------- */
+/* Host input prep (CPU only; renderer/scene.cpp, renderer/lights.cpp,         */
+/* geometry/geometryhelpers.cpp). See szg/host.h.                              */
+/* ------------------------------------------------------------------------- */
+
+#ifdef __cplusplus
+} /* extern "C" */
+
+static_assert(sizeof(szg_camera_packed) == 416, "gputypes.hpp:36");
+static_assert(sizeof(szg_atmosphere_packed) == 128, "gputypes.hpp:72");
+static_assert(sizeof(szg_directional_light_packed) == 176, "gputypes.hpp:90");
+static_assert(sizeof(szg_spot_light_packed) == 192, "gputypes.hpp:115");
+static_assert(sizeof(szg_pc_transmittance) == 16, "skyview.hpp:64-72");
+static_assert(sizeof(szg_pc_skyview) == 32, "skyview.hpp:89-96");
+static_assert(sizeof(szg_pc_composite) == 64, "skyview.hpp:125-144");
+static_assert(sizeof(szg_pc_lights) == 64, "deferred.hpp:82-98");
+static_assert(offsetof(szg_pc_composite, drawExtent) == 24 && offsetof(szg_pc_composite, gbufferExtent) == 40 &&
+                  offsetof(szg_pc_composite, directionalLights) == 48 && offsetof(szg_pc_composite, sunLightIndex) == 56,
+              "camera.comp:50-67 std430 offsets");
+static_assert(offsetof(szg_pc_lights, directionalLightsBuffer) == 16 && offsetof(szg_pc_lights, directionalLightCount) == 32 &&
+                  offsetof(szg_pc_lights, gbufferOffset) == 48 && offsetof(szg_pc_lights, gbufferExtent) == 56,
+              "lights.comp:41-57 std430 offsets");
+#endif
+
+#endif /* SZG_ABI_H */

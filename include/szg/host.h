@@ -1,0 +1,132 @@
+/*
+ * szg/host.h — host-side input preparation (CPU only): scene parameters ->
+ * the packed blocks of szg/abi.h. Restates the glm-based helpers of the
+ * reference (glm 1.0.1, cmake/dependencies.cmake:39-46, is not vendored; its
+ * published formulas are restated, compile definitions
+ * GLM_FORCE_DEPTH_ZERO_TO_ONE / GLM_FORCE_RADIANS: syzygy/CMakeLists.txt:81-94).
+ *
+ * Pinned by the reference's own 22 euler known-answer cases
+ * (geometry/geometrytests.cpp:120-186) for the euler<->forward convention;
+ * projection / inverse are unpinned by the reference and are checked against an
+ * independent numpy restatement in tests/.
+ */
+#ifndef SZG_HOST_H
+#define SZG_HOST_H
+
+#include "szg/abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* geometry/geometrystatics.hpp:7-9 */
+#define SZG_WORLD_FORWARD_X 0.0f
+#define SZG_WORLD_FORWARD_Y 0.0f
+#define SZG_WORLD_FORWARD_Z 1.0f
+#define SZG_WORLD_UP_X 0.0f
+#define SZG_WORLD_UP_Y (-1.0f)
+#define SZG_WORLD_UP_Z 0.0f
+
+/* geometry/geometrytypes.hpp:22-38 */
+typedef struct szg_aabb
+{
+    float center[3];
+    float half_extent[3];
+} szg_aabb;
+
+/* renderer/scene.hpp Atmosphere (defaults scene.cpp:52-75) */
+typedef struct szg_atmosphere
+{
+    float sunEulerAngles[3]; /* (pitch, roll, yaw) */
+    float planetRadiusMegameters;
+    float atmosphereRadiusMegameters;
+    float groundColor[3]; /* not sent to the device (scene.cpp:701-715) */
+    float scatteringRayleighPerMegameter[3];
+    float absorptionRayleighPerMegameter[3];
+    float altitudeDecayRayleighMegameters;
+    float scatteringMiePerMegameter[3];
+    float absorptionMiePerMegameter[3];
+    float altitudeDecayMieMegameters;
+    float scatteringOzonePerMegameter[3];
+    float absorptionOzonePerMegameter[3];
+    float sunIntensitySpectrum[3];
+    float sunAngularRadius;
+} szg_atmosphere;
+
+/* renderer/scene.hpp Camera (defaults scene.cpp:77-83) */
+typedef struct szg_camera
+{
+    float cameraPosition[3];
+    float eulerAngles[3];
+    float fovDegrees;
+    float near_plane;
+    float far_plane;
+    uint32_t orthographic;
+} szg_camera;
+
+/* renderer/lights.hpp:18-30 */
+typedef struct szg_spotlight_params
+{
+    float color[4];
+    float strength;
+    float falloffFactor;
+    float falloffDistance;
+    float verticalFOVDegrees;
+    float horizontalScale;
+    float eulerAngles[3];
+    float position[3];
+    float near_plane;
+    float far_plane;
+} szg_spotlight_params;
+
+/* renderer/scene.hpp SunAnimation (defaults scene.cpp:87-91) */
+typedef struct szg_sun_animation
+{
+    uint32_t frozen;
+    float time;
+    float speed;
+    uint32_t skipNight;
+} szg_sun_animation;
+
+/* geometryhelpers.cpp:102-105 / :107-145 */
+void szg_forward_from_eulers(const float eulers[3], float out_forward[3]);
+void szg_eulers_from_forward(const float forward[3], float out_eulers[3]);
+/* geometryhelpers.cpp:83-95 (perspectiveLH_ZO with near/far swapped: reverse-Z) */
+void szg_projection_vk(float fov_y_degrees, float aspect, float near_plane, float far_plane, szg_mat4* out);
+/* geometryhelpers.cpp:97-100 */
+void szg_projection_ortho_vk(const float min[3], const float max[3], szg_mat4* out);
+/* geometryhelpers.cpp:147-157 */
+void szg_transform_vk(const float position[3], const float eulers[3], szg_mat4* out);
+void szg_view_vk(const float position[3], const float eulers[3], szg_mat4* out);
+/* geometryhelpers.cpp:171-204 */
+void szg_projection_ortho_aabb_vk(const szg_mat4* view, const szg_aabb* bounds, szg_mat4* out);
+/* glm::inverse / glm::inverseTranspose / operator* on mat4 */
+void szg_mat4_inverse(const szg_mat4* m, szg_mat4* out);
+void szg_mat4_inverse_transpose(const szg_mat4* m, szg_mat4* out);
+void szg_mat4_mul(const szg_mat4* a, const szg_mat4* b, szg_mat4* out);
+
+/* scene.cpp:52-75, :77-83, :87-91 */
+void szg_atmosphere_default_earth(szg_atmosphere* out);
+void szg_camera_default(szg_camera* out);
+void szg_sun_animation_default(szg_sun_animation* out);
+/* scene.cpp:689-692, :694-716, :718-737 (index 0 = sun, 1 = moon: renderer.cpp:312-329) */
+void szg_atmosphere_direction_to_sun(const szg_atmosphere* a, float out[3]);
+void szg_atmosphere_to_device_equivalent(const szg_atmosphere* a, szg_atmosphere_packed* out);
+void szg_atmosphere_baked(const szg_atmosphere* a, const szg_aabb* scene_bounds, szg_atmosphere_packed* out_atmosphere,
+                          szg_directional_light_packed* out_sunlight, szg_directional_light_packed* out_moonlight);
+/* scene.cpp:739-794 */
+void szg_camera_to_device_equivalent(const szg_camera* c, float aspect_ratio, szg_camera_packed* out);
+/* lights.cpp:9-27, :29-46 */
+void szg_make_directional(const float color[4], float strength, const float eulers[3], const szg_aabb* captured_bounds,
+                          szg_directional_light_packed* out);
+void szg_make_spot(const szg_spotlight_params* params, szg_spot_light_packed* out);
+/* scene.cpp:218-229 addSpotlight defaults (strength 1000, falloff 1/1, fov 30, near .1, far 1000) */
+void szg_spotlight_params_default(const float color_rgb[3], const float position[3], const float eulers[3],
+                                  szg_spotlight_params* out);
+/* scene.cpp:532-574: advance the sun animation by dt seconds and set sunEulerAngles.x */
+void szg_scene_tick_sun(szg_sun_animation* anim, szg_atmosphere* atmosphere, double delta_time_seconds);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SZG_HOST_H */

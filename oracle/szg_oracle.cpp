@@ -1,0 +1,1576 @@
+// =============================================================================
+// szg_oracle.cpp — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Scalar CPU restatement of the reference's GLSL for the deferred-shading +
+// atmosphere path. Only tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg may build, load or call this file; the product
+// (syzygy_amd/, include/) never does.
+//
+// PARITY PINNING: the reference holds no golden vectors, known-answer tests or
+// fixtures for this path and its shaders cannot be compiled or
+// run here (GLSL + Vulkan 1.3; glslang/Vulkan/glm absent, FetchContent needs a
+// network). So this oracle is pinned by (a) line-by-line review against the
+// files cited at every function, (b) closed-form anchors and structural
+// properties checked in tests/test_oracle.py (zenith optical depth, uv<->(r,mu)
+// round trip, top-of-atmosphere T=1, light linearity, sky-view mirror symmetry)
+// — i.e. "parity unpinned by reference tests"; see DESIGN.md.
+//
+// Numerics: every GLSL operation is evaluated in fp32 in the order written in
+// the shader; compile with -O2 -ffp-contract=off (no FMA contraction, no
+// fast-math). Built-ins use the correctly rounded fp32 libm functions (expf,
+// powf, sinf, cosf, asinf, acosf, sqrtf). Sampler semantics are SURVEY
+// Appendix A: fp32 bilinear with clamp-to-edge, nearest clamp-to-edge, nearest
+// clamp-to-border(0); UNORM16 store = RTE(clamp(x,0,1)*65535).
+//
+// All paths are relative to the reference checkout: shaders/... .
+// =============================================================================
+
+#include "szg/abi.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <functional>
+#include <thread>
+#include <vector>
+
+namespace
+{
+// ----------------------------------------------------------------------------
+// GLSL vector types and built-ins
+// ----------------------------------------------------------------------------
+struct vec2
+{
+    float x, y;
+};
+struct vec3
+{
+    float x, y, z;
+    vec3() = default;
+    constexpr vec3(float a, float b, float c) : x(a), y(b), z(c) {}
+    explicit constexpr vec3(float a) : x(a), y(a), z(a) {}
+};
+struct vec4
+{
+    float x, y, z, w;
+};
+
+inline vec2 operator+(vec2 a, vec2 b) { return {a.x + b.x, a.y + b.y}; }
+inline vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
+inline vec2 operator*(vec2 a, float s) { return {a.x * s, a.y * s}; }
+inline float dot(vec2 a, vec2 b) { return a.x * b.x + a.y * b.y; }
+
+inline vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+inline vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+inline vec3 operator-(vec3 a) { return {-a.x, -a.y, -a.z}; }
+inline vec3 operator*(vec3 a, vec3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+inline vec3 operator/(vec3 a, vec3 b) { return {a.x / b.x, a.y / b.y, a.z / b.z}; }
+inline vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+inline vec3 operator*(float s, vec3 a) { return {s * a.x, s * a.y, s * a.z}; }
+inline vec3 operator/(vec3 a, float s) { return {a.x / s, a.y / s, a.z / s}; }
+inline vec3 operator+(vec3 a, float s) { return {a.x + s, a.y + s, a.z + s}; }
+inline vec3& operator+=(vec3& a, vec3 b)
+{
+    a = a + b;
+    return a;
+}
+inline vec3& operator*=(vec3& a, vec3 b)
+{
+    a = a * b;
+    return a;
+}
+
+inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float length(vec3 a) { return sqrtf(dot(a, a)); }
+inline float length(vec2 a) { return sqrtf(dot(a, a)); }
+inline float distance(vec3 a, vec3 b) { return length(a - b); }
+inline float distance(vec2 a, vec2 b) { return length(a - b); }
+inline float inversesqrt(float x) { return 1.0f / sqrtf(x); }
+// normalize(v) = v * inversesqrt(dot(v, v))
+inline vec3 normalize(vec3 v) { return v * inversesqrt(dot(v, v)); }
+inline vec2 normalize(vec2 v) { return v * inversesqrt(dot(v, v)); }
+inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+inline vec3 clamp(vec3 v, float lo, float hi) { return {clampf(v.x, lo, hi), clampf(v.y, lo, hi), clampf(v.z, lo, hi)}; }
+// mix(a, b, w) = a*(1-w) + b*w
+inline vec3 mix(vec3 a, vec3 b, vec3 w)
+{
+    return {a.x * (1.0f - w.x) + b.x * w.x, a.y * (1.0f - w.y) + b.y * w.y, a.z * (1.0f - w.z) + b.z * w.z};
+}
+inline vec3 mix(vec3 a, vec3 b, float w) { return mix(a, b, vec3(w)); }
+inline float smoothstep(float e0, float e1, float x)
+{
+    float const t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+inline vec3 exp3(vec3 v) { return {expf(v.x), expf(v.y), expf(v.z)}; }
+inline vec3 pow3(vec3 v, float e) { return {powf(v.x, e), powf(v.y, e), powf(v.z, e)}; }
+
+struct mat4
+{
+    float m[16]; // column-major
+};
+inline mat4 load(const szg_mat4& s)
+{
+    mat4 r;
+    std::memcpy(r.m, s.m, sizeof r.m);
+    return r;
+}
+// mat4 * vec4 = sum of columns scaled by the components, left to right
+inline vec4 operator*(const mat4& a, vec4 v)
+{
+    vec4 r;
+    r.x = a.m[0] * v.x + a.m[4] * v.y + a.m[8] * v.z + a.m[12] * v.w;
+    r.y = a.m[1] * v.x + a.m[5] * v.y + a.m[9] * v.z + a.m[13] * v.w;
+    r.z = a.m[2] * v.x + a.m[6] * v.y + a.m[10] * v.z + a.m[14] * v.w;
+    r.w = a.m[3] * v.x + a.m[7] * v.y + a.m[11] * v.z + a.m[15] * v.w;
+    return r;
+}
+// mat4 * mat4: column j of the result = a * (column j of b)
+inline mat4 operator*(const mat4& a, const mat4& b)
+{
+    mat4 r;
+    for (int j = 0; j < 4; j++)
+    {
+        vec4 const c = a * vec4{b.m[j * 4 + 0], b.m[j * 4 + 1], b.m[j * 4 + 2], b.m[j * 4 + 3]};
+        r.m[j * 4 + 0] = c.x;
+        r.m[j * 4 + 1] = c.y;
+        r.m[j * 4 + 2] = c.z;
+        r.m[j * 4 + 3] = c.w;
+    }
+    return r;
+}
+
+// ----------------------------------------------------------------------------
+// Formats
+// ----------------------------------------------------------------------------
+inline float half_to_float(uint16_t h)
+{
+    uint32_t const sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t const exp = (h >> 10) & 0x1Fu;
+    uint32_t const man = h & 0x3FFu;
+    uint32_t bits;
+    if (exp == 0)
+    {
+        if (man == 0)
+        {
+            bits = sign;
+        }
+        else
+        {
+            // subnormal: value = man * 2^-24
+            float const f = (float)man * (1.0f / 16777216.0f);
+            uint32_t fb;
+            std::memcpy(&fb, &f, 4);
+            bits = sign | fb;
+        }
+    }
+    else if (exp == 31)
+    {
+        bits = sign | 0x7F800000u | (man << 13);
+    }
+    else
+    {
+        bits = sign | ((exp + 112u) << 23) | (man << 13);
+    }
+    float out;
+    std::memcpy(&out, &bits, 4);
+    return out;
+}
+
+// fp32 -> fp16, round to nearest even (colour-attachment write)
+inline uint16_t float_to_half(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    uint32_t const sign = (x >> 16) & 0x8000u;
+    uint32_t const absx = x & 0x7FFFFFFFu;
+    if (absx >= 0x7F800000u)
+    {
+        return (uint16_t)(sign | 0x7C00u | ((absx > 0x7F800000u) ? 0x200u : 0u));
+    }
+    if (absx >= 0x477FF000u)
+    {
+        // >= 65520 rounds to infinity
+        return (uint16_t)(sign | 0x7C00u);
+    }
+    if (absx < 0x33000001u)
+    {
+        // <= 2^-25 rounds to zero
+        return (uint16_t)sign;
+    }
+    int32_t const e = (int32_t)(absx >> 23) - 127;
+    uint32_t man = (absx & 0x7FFFFFu) | 0x800000u;
+    int shift;
+    uint32_t hexp;
+    if (e < -14)
+    {
+        shift = 13 + (-14 - e);
+        hexp = 0;
+    }
+    else
+    {
+        shift = 13;
+        hexp = (uint32_t)(e + 15);
+    }
+    uint32_t const halfway = 1u << (shift - 1);
+    uint32_t const rem = man & ((1u << shift) - 1u);
+    uint32_t q = man >> shift;
+    if (rem > halfway || (rem == halfway && (q & 1u)))
+    {
+        q += 1;
+    }
+    uint32_t h;
+    if (hexp == 0)
+    {
+        h = q; // subnormal (may carry into the smallest normal, which is correct)
+    }
+    else
+    {
+        h = ((hexp - 1) << 10) + q; // q has the implicit bit at 0x400
+    }
+    return (uint16_t)(sign | h);
+}
+
+// imageStore on rgba16 (UNORM16): clamp, scale, round-to-nearest-even
+inline uint16_t unorm16_store(float x)
+{
+    float const c = fminf(fmaxf(x, 0.0f), 1.0f); // fmaxf(NaN, 0) = 0
+    return (uint16_t)nearbyintf(c * 65535.0f);
+}
+inline float unorm16_load(uint16_t q) { return (float)q / 65535.0f; }
+
+struct Image
+{
+    const uint8_t* data;
+    uint32_t width, height, pitch;
+};
+inline Image img(const szg_image& s) { return {(const uint8_t*)s.data, s.width, s.height, s.pitch_bytes}; }
+
+inline vec4 texel_rgba32f(const Image& im, int x, int y)
+{
+    const float* p = (const float*)(im.data + (size_t)y * im.pitch) + (size_t)x * 4;
+    return {p[0], p[1], p[2], p[3]};
+}
+inline vec4 texel_rgba16f(const Image& im, int x, int y)
+{
+    const uint16_t* p = (const uint16_t*)(im.data + (size_t)y * im.pitch) + (size_t)x * 4;
+    return {half_to_float(p[0]), half_to_float(p[1]), half_to_float(p[2]), half_to_float(p[3])};
+}
+
+// texture() NEAREST / CLAMP_TO_EDGE (gbuffer.cpp:104-109)
+inline void nearest_edge(const Image& im, vec2 uv, int& x, int& y)
+{
+    x = (int)floorf(uv.x * (float)im.width);
+    y = (int)floorf(uv.y * (float)im.height);
+    x = std::min(std::max(x, 0), (int)im.width - 1);
+    y = std::min(std::max(y, 0), (int)im.height - 1);
+}
+
+// texture() NEAREST / CLAMP_TO_BORDER(0) on D32F (shadowpass.cpp:29-35, scenetexture.cpp:150-155)
+inline float sample_depth_border(const Image& im, vec2 uv)
+{
+    // floorf of a huge/NaN coordinate: compare in float first so the int cast is defined
+    float const fx = floorf(uv.x * (float)im.width);
+    float const fy = floorf(uv.y * (float)im.height);
+    if (!(fx >= 0.0f) || !(fy >= 0.0f) || !(fx < (float)im.width) || !(fy < (float)im.height))
+    {
+        return 0.0f;
+    }
+    const float* row = (const float*)(im.data + (size_t)(int)fy * im.pitch);
+    return row[(int)fx];
+}
+
+// texture() LINEAR / CLAMP_TO_EDGE, no mips, fp32 weights (skyview.cpp:199-207, :339-346)
+inline vec3 sample_linear_rgb(const Image& im, vec2 st)
+{
+    float const u = st.x * (float)im.width - 0.5f;
+    float const v = st.y * (float)im.height - 0.5f;
+    float const fu = floorf(u);
+    float const fv = floorf(v);
+    float const a = u - fu;
+    float const b = v - fv;
+    int i0 = (int)fu, j0 = (int)fv;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    int const W = (int)im.width, H = (int)im.height;
+    i0 = std::min(std::max(i0, 0), W - 1);
+    i1 = std::min(std::max(i1, 0), W - 1);
+    j0 = std::min(std::max(j0, 0), H - 1);
+    j1 = std::min(std::max(j1, 0), H - 1);
+    vec4 const t00 = texel_rgba32f(im, i0, j0);
+    vec4 const t10 = texel_rgba32f(im, i1, j0);
+    vec4 const t01 = texel_rgba32f(im, i0, j1);
+    vec4 const t11 = texel_rgba32f(im, i1, j1);
+    float const w00 = (1.0f - a) * (1.0f - b);
+    float const w10 = a * (1.0f - b);
+    float const w01 = (1.0f - a) * b;
+    float const w11 = a * b;
+    vec3 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    return r;
+}
+
+// ----------------------------------------------------------------------------
+// shaders/types/atmosphere.glinl:3-32
+// ----------------------------------------------------------------------------
+struct Atmosphere
+{
+    vec3 scatteringRayleighPerMm;
+    float densityScaleRayleighMm;
+    vec3 absorptionRayleighPerMm;
+    float planetRadiusMm;
+    vec3 scatteringMiePerMm;
+    float densityScaleMieMm;
+    vec3 absorptionMiePerMm;
+    float atmosphereRadiusMm;
+    vec3 incidentDirectionSun;
+    vec3 scatteringOzonePerMm;
+    vec3 absorptionOzonePerMm;
+    vec3 sunIntensitySpectrum;
+    float sunAngularRadius;
+};
+inline vec3 v3(const float* p) { return {p[0], p[1], p[2]}; }
+Atmosphere load(const szg_atmosphere_packed& s)
+{
+    Atmosphere a;
+    a.scatteringRayleighPerMm = v3(s.scatteringRayleighPerMm);
+    a.densityScaleRayleighMm = s.densityScaleRayleighMm;
+    a.absorptionRayleighPerMm = v3(s.absorptionRayleighPerMm);
+    a.planetRadiusMm = s.planetRadiusMm;
+    a.scatteringMiePerMm = v3(s.scatteringMiePerMm);
+    a.densityScaleMieMm = s.densityScaleMieMm;
+    a.absorptionMiePerMm = v3(s.absorptionMiePerMm);
+    a.atmosphereRadiusMm = s.atmosphereRadiusMm;
+    a.incidentDirectionSun = v3(s.incidentDirectionSun);
+    a.scatteringOzonePerMm = v3(s.scatteringOzonePerMm);
+    a.absorptionOzonePerMm = v3(s.absorptionOzonePerMm);
+    a.sunIntensitySpectrum = v3(s.sunIntensitySpectrum);
+    a.sunAngularRadius = s.sunAngularRadius;
+    return a;
+}
+
+// The transmittance LUT as a sampler2D plus the compile-time constants
+// TRANSMITTANCE_LUT_WIDTH/HEIGHT (common.glinl:13-14), which here are the
+// LUT's runtime dimensions (512x128 in the reference).
+struct TransmittanceLUT
+{
+    Image image;
+    int width, height;
+};
+
+constexpr float METERS_PER_MM = 1000000.0f;       // common.glinl:16
+constexpr float PI = 3.141592653589793f;          // common.glinl:18
+constexpr uint32_t SKY_VIEW_LUT_SAMPLE_COUNT = 32; // common.glinl:363
+
+// common.glinl:23-26
+inline float safeSqrt(float value) { return sqrtf(fmaxf(value, 0.0f)); }
+// common.glinl:29-32
+inline float textureCoordFromUnitRange(float value, int dimension)
+{
+    return 0.5f / (float)dimension + value * (1.0f - 1.0f / (float)dimension);
+}
+// common.glinl:33-36
+inline float unitRangeFromTextureCoord(float texCoord, int dimension)
+{
+    return (texCoord - 0.5f / (float)dimension) / (1.0f - 1.0f / (float)dimension);
+}
+
+// common.glinl:40-66
+vec2 transmittanceLUT_RMu_to_UV(const Atmosphere& atmosphere, const TransmittanceLUT& lut, float radius, float mu)
+{
+    float const atmospherRadiusMmSquared = atmosphere.atmosphereRadiusMm * atmosphere.atmosphereRadiusMm;
+    float const planetRadiusMmSquared = atmosphere.planetRadiusMm * atmosphere.planetRadiusMm;
+    float const H = safeSqrt(atmospherRadiusMmSquared - planetRadiusMmSquared);
+    float const rho = safeSqrt(radius * radius - planetRadiusMmSquared);
+    float const d = fmaxf(-radius * mu + safeSqrt(radius * radius * (mu * mu - 1.0f) + atmospherRadiusMmSquared), 0.0f);
+    float const d_min = atmosphere.atmosphereRadiusMm - radius;
+    float const d_max = rho + H;
+    float const x_mu = (d - d_min) / (d_max - d_min);
+    float const x_radius = rho / H;
+    return {textureCoordFromUnitRange(x_mu, lut.width), textureCoordFromUnitRange(x_radius, lut.height)};
+}
+
+// common.glinl:69-102
+vec2 transmittanceLUT_UV_to_RMu(const Atmosphere& atmosphere, int lutWidth, int lutHeight, vec2 uv)
+{
+    float const x_mu = unitRangeFromTextureCoord(uv.x, lutWidth);
+    float const x_radius = unitRangeFromTextureCoord(uv.y, lutHeight);
+    float const atmospherRadiusMmSquared = atmosphere.atmosphereRadiusMm * atmosphere.atmosphereRadiusMm;
+    float const planetRadiusMmSquared = atmosphere.planetRadiusMm * atmosphere.planetRadiusMm;
+    float const H = safeSqrt(atmospherRadiusMmSquared - planetRadiusMmSquared);
+    float const rho = H * x_radius;
+    float const radius = sqrtf(rho * rho + planetRadiusMmSquared);
+    float const d_min = atmosphere.atmosphereRadiusMm - radius;
+    float const d_max = rho + H;
+    float const d = (d_max - d_min) * x_mu + d_min;
+    if (d == 0.0f)
+    {
+        return {radius, 1.0f};
+    }
+    float const mu = (H * H - rho * rho - d * d) / (2.0f * radius * d);
+    return {radius, clampf(mu, -1.0f, 1.0f)};
+}
+
+// common.glinl:104-112
+vec3 sampleTransmittanceLUT_Ray(const TransmittanceLUT& LUT, const Atmosphere& atmosphere, vec3 position, vec3 direction)
+{
+    float const radius = length(position);
+    float const mu = (dot(position, direction) / (length(position) * length(direction)));
+    vec2 const uv = transmittanceLUT_RMu_to_UV(atmosphere, LUT, radius, mu);
+    return sample_linear_rgb(LUT.image, uv);
+}
+
+// common.glinl:114-136
+vec3 sampleTransmittanceLUT_Segment(const TransmittanceLUT& LUT, const Atmosphere& atmosphere, vec3 from, vec3 to)
+{
+    vec3 transmittance;
+    vec3 const direction = normalize(to - from);
+    if (dot(from, direction) < 0.0f)
+    {
+        transmittance = sampleTransmittanceLUT_Ray(LUT, atmosphere, to, -direction) /
+                        sampleTransmittanceLUT_Ray(LUT, atmosphere, from, -direction);
+    }
+    else
+    {
+        transmittance = sampleTransmittanceLUT_Ray(LUT, atmosphere, from, direction) /
+                        sampleTransmittanceLUT_Ray(LUT, atmosphere, to, direction);
+    }
+    return clamp(transmittance, 0.0f, 1.0f);
+}
+
+// common.glinl:138-143
+vec3 sampleTransmittanceLUT_RadiusMu(const TransmittanceLUT& LUT, const Atmosphere& atmosphere, float radius, float mu)
+{
+    vec2 const uv = transmittanceLUT_RMu_to_UV(atmosphere, LUT, radius, mu);
+    return sample_linear_rgb(LUT.image, uv);
+}
+
+// common.glinl:145-172
+vec3 sampleTransmittanceLUT_Sun(const TransmittanceLUT& LUT, const Atmosphere& atmosphere, float radius, float cos_sunZenith)
+{
+    float const sin_sunRadius = sinf(atmosphere.sunAngularRadius);
+    float const cos_sunRadius = cosf(atmosphere.sunAngularRadius);
+    float const sin_horizonZenith = atmosphere.planetRadiusMm / radius;
+    float const cos_horizonZenith = -safeSqrt(1.0f - sin_horizonZenith * sin_horizonZenith);
+    vec3 const transmittanceThroughAtmosphere = sampleTransmittanceLUT_RadiusMu(LUT, atmosphere, radius, cos_sunZenith);
+    float const angularFactor = smoothstep(-sin_horizonZenith * sin_sunRadius, sin_horizonZenith * sin_sunRadius,
+                                           cos_sunZenith - cos_horizonZenith * cos_sunRadius);
+    return transmittanceThroughAtmosphere * angularFactor;
+}
+
+// common.glinl:174-177
+inline float densityExponential(float altitude, float densityScale) { return expf(-altitude / densityScale); }
+// common.glinl:180
+inline float densityTent(float altitude_km) { return fmaxf(0.0f, 1.0f - fabsf(altitude_km - 25.0f) / 15.0f); }
+
+// common.glinl:182-191
+struct ExtinctionSample
+{
+    vec3 scatteringRayleigh;
+    vec3 scatteringMie;
+    vec3 absorptionMie;
+    vec3 absorptionOzone;
+    vec3 extinction;
+};
+
+// common.glinl:194-216 (Q1: absorptionMie uses absorptionRayleighPerMm, line 202)
+ExtinctionSample sampleExtinction(const Atmosphere& atmosphere, float altitude_Mm)
+{
+    float const densityRayleigh = densityExponential(altitude_Mm, atmosphere.densityScaleRayleighMm);
+    vec3 const scatteringRayleigh = atmosphere.scatteringRayleighPerMm * densityRayleigh;
+    vec3 const absorptionRayleigh = atmosphere.absorptionRayleighPerMm * densityRayleigh;
+
+    float const densityMie = densityExponential(altitude_Mm, atmosphere.densityScaleMieMm);
+    vec3 const scatteringMie = atmosphere.scatteringMiePerMm * densityMie;
+    vec3 const absorptionMie = atmosphere.absorptionRayleighPerMm * densityMie;
+
+    float const densityOzone = densityTent(altitude_Mm * 1000.0f);
+    vec3 const scatteringOzone = atmosphere.scatteringOzonePerMm * densityOzone;
+    vec3 const absorptionOzone = atmosphere.absorptionOzonePerMm * densityOzone;
+
+    ExtinctionSample s;
+    s.scatteringRayleigh = scatteringRayleigh;
+    s.scatteringMie = scatteringMie;
+    s.absorptionMie = absorptionMie;
+    s.absorptionOzone = absorptionOzone;
+    s.extinction = scatteringRayleigh + absorptionRayleigh + scatteringMie + absorptionMie + scatteringOzone + absorptionOzone;
+    return s;
+}
+
+// common.glinl:220-260
+bool raySphereIntersection(vec3 rayOrigin, vec3 rayDirectionNormalized, float radius, float& t0, float& t1)
+{
+    vec3 const f = rayOrigin;
+    vec3 const d = rayDirectionNormalized;
+    float const b = -1.0f * dot(f, d);
+    vec3 const centerToIntersectionChord = f + b * d;
+    float const discriminant = radius * radius - dot(centerToIntersectionChord, centerToIntersectionChord);
+    float const c = dot(f, f) - radius * radius;
+    if (discriminant < 0.0f)
+    {
+        return false;
+    }
+    float q = b;
+    if (b < 0.0f)
+    {
+        q -= sqrtf(discriminant);
+    }
+    else
+    {
+        q += sqrtf(discriminant);
+    }
+    t0 = c / q;
+    t1 = q;
+    if (t0 > t1)
+    {
+        float const temp = t0;
+        t0 = t1;
+        t1 = temp;
+    }
+    return true;
+}
+
+// common.glinl:263-269
+inline float phaseRayleigh(float cosine)
+{
+    float const scalar = 3.0f / (16.0f * PI);
+    float const numerator = (1.0f + cosine * cosine);
+    return scalar * numerator;
+}
+// common.glinl:273-279
+inline float phaseMie(float cosine, float g)
+{
+    float const scalar = 3.0f / (8.0f * PI);
+    float const numerator = (1.0f - g * g) * (1.0f + cosine * cosine);
+    float const denominator = (2.0f + g * g) * powf(1.0f + g * g - 2.0f * g * cosine, 1.5f);
+    return scalar * numerator / denominator;
+}
+
+// common.glinl:284-307. Out parameters that the GLSL leaves unwritten on a miss
+// are undefined there; they start at 0 here and the results that depend on them
+// are never consumed (hitAtmosphere / hitPlanet gate them).
+void raycastAtmosphere(const Atmosphere& atmosphere, vec3 origin, vec3 direction, float& atmosphereDistance)
+{
+    float atmosphere_t0 = 0.0f, atmosphere_t1 = 0.0f;
+    bool const hitAtmosphere =
+        raySphereIntersection(origin, direction, atmosphere.atmosphereRadiusMm, atmosphere_t0, atmosphere_t1) &&
+        atmosphere_t1 > 0.0f;
+    atmosphereDistance = 0.0f;
+    atmosphere_t0 = fmaxf(0.0f, atmosphere_t0);
+    float planet_t0 = 0.0f, planet_t1 = 0.0f;
+    bool const hitPlanet =
+        raySphereIntersection(origin, direction, atmosphere.planetRadiusMm, planet_t0, planet_t1) && planet_t0 > 0.0f;
+    if (hitPlanet)
+    {
+        atmosphere_t1 = fminf(planet_t0, atmosphere_t1);
+    }
+    if (hitAtmosphere)
+    {
+        atmosphereDistance = atmosphere_t1 - atmosphere_t0;
+    }
+}
+
+// common.glinl:309-314
+struct RaymarchStep
+{
+    float radius;
+    float mu;
+    float mu_sun;
+};
+
+// common.glinl:316-334 (Q2: the square root of cos(a+b) is kept as written)
+RaymarchStep stepRadiusMu(RaymarchStep start, float stepDistance)
+{
+    float const mu_sunAndStepDirection =
+        safeSqrt(start.mu_sun * start.mu - safeSqrt((1.0f - start.mu_sun * start.mu_sun) * (1.0f - start.mu * start.mu)));
+    RaymarchStep result;
+    result.radius =
+        safeSqrt(stepDistance * stepDistance + 2.0f * start.radius * start.mu * stepDistance + start.radius * start.radius);
+    result.mu = (start.radius * start.mu + stepDistance) / result.radius;
+    result.mu_sun = (start.radius * start.mu_sun + stepDistance * mu_sunAndStepDirection) / result.radius;
+    return result;
+}
+
+// common.glinl:336-361
+vec3 sampleTransmittanceLUT_RayMarchStep(const Atmosphere& atmosphere, const TransmittanceLUT& LUT, RaymarchStep start,
+                                         float stepDistance)
+{
+    if (stepDistance < 0.0000001f)
+    {
+        return vec3(1.0f);
+    }
+    RaymarchStep const end = stepRadiusMu(start, stepDistance);
+    vec3 transmittance;
+    if (start.mu > 0.0f)
+    {
+        transmittance = sampleTransmittanceLUT_RadiusMu(LUT, atmosphere, start.radius, start.mu) /
+                        sampleTransmittanceLUT_RadiusMu(LUT, atmosphere, end.radius, end.mu);
+    }
+    else
+    {
+        transmittance = sampleTransmittanceLUT_RadiusMu(LUT, atmosphere, end.radius, -end.mu) /
+                        sampleTransmittanceLUT_RadiusMu(LUT, atmosphere, start.radius, -start.mu);
+    }
+    return clamp(transmittance, 0.0f, 1.0f);
+}
+
+// common.glinl:364-424
+vec3 computeLuminanceScatteringIntegral(const Atmosphere& atmosphere, const TransmittanceLUT& transmittanceLUT, vec3 origin,
+                                        vec3 direction, float sampleDistance)
+{
+    vec3 const scatteringDir = -normalize(direction);
+    float const radius = length(origin);
+    float const mu = dot(origin, direction) / (length(origin) * length(direction));
+    float const mu_sun =
+        dot(origin, -atmosphere.incidentDirectionSun) / (length(origin) * length(atmosphere.incidentDirectionSun));
+    RaymarchStep const originStep{radius, mu, mu_sun};
+
+    vec3 luminance = vec3(0.0f);
+    float const dSampleDistance = sampleDistance / (float)SKY_VIEW_LUT_SAMPLE_COUNT;
+    for (uint32_t i = 0; i < SKY_VIEW_LUT_SAMPLE_COUNT; i++)
+    {
+        float const t = (float)i * dSampleDistance;
+        vec3 const begin = origin - ((float)i * dSampleDistance) * scatteringDir;
+        vec3 const end = origin - ((float)(i + 1) * dSampleDistance) * scatteringDir;
+
+        RaymarchStep const sampleStep = stepRadiusMu(originStep, t);
+        float const altitude = length(begin) - atmosphere.planetRadiusMm;
+        vec3 const transmittanceToSun =
+            sampleTransmittanceLUT_Sun(transmittanceLUT, atmosphere, sampleStep.radius, sampleStep.mu_sun);
+        ExtinctionSample const extinctionSample = sampleExtinction(atmosphere, altitude);
+
+        vec3 const transmittanceToBegin = sampleTransmittanceLUT_RayMarchStep(atmosphere, transmittanceLUT, originStep, t);
+        float const incidentCosine = dot(atmosphere.incidentDirectionSun, scatteringDir);
+        vec3 const phaseTimesScattering = extinctionSample.scatteringRayleigh * phaseRayleigh(incidentCosine) +
+                                          extinctionSample.scatteringMie * phaseMie(incidentCosine, 0.8f);
+        vec3 const shadowing = transmittanceToSun;
+
+        vec3 const transmittanceAlongPath = sampleTransmittanceLUT_Segment(transmittanceLUT, atmosphere, begin, end);
+        vec3 const scatteringIlluminanceIntegral = (vec3(1.0f) - transmittanceAlongPath) / extinctionSample.extinction;
+
+        luminance += phaseTimesScattering * shadowing * scatteringIlluminanceIntegral * transmittanceToBegin;
+    }
+    return luminance;
+}
+
+// ----------------------------------------------------------------------------
+// Row-parallel helper for the timed CPU baseline (plain std::thread split)
+// ----------------------------------------------------------------------------
+void parallel_rows(uint32_t rows, int threads, const std::function<void(uint32_t, uint32_t)>& fn)
+{
+    if (threads <= 1 || rows < 2)
+    {
+        fn(0, rows);
+        return;
+    }
+    uint32_t const n = (uint32_t)std::min<uint32_t>((uint32_t)threads, rows);
+    std::vector<std::thread> pool;
+    pool.reserve(n);
+    // interleaved row chunks so that sky and geometry rows are spread evenly
+    for (uint32_t t = 0; t < n; t++)
+    {
+        pool.emplace_back([=, &fn]() {
+            uint32_t const chunk = 4;
+            for (uint32_t r0 = t * chunk; r0 < rows; r0 += n * chunk)
+            {
+                fn(r0, std::min(rows, r0 + chunk));
+            }
+        });
+    }
+    for (auto& th : pool)
+    {
+        th.join();
+    }
+}
+
+// transmittance_LUT.comp:55-106, one texel
+vec4 transmittance_texel(const Atmosphere& atmosphere, int W, int H, int tx, int ty)
+{
+    int const SAMPLE_COUNT = 500; // transmittance_LUT.comp:53
+    vec2 const size{(float)W, (float)H};
+    vec2 const uv{((float)tx + 0.5f) / size.x, ((float)ty + 0.5f) / size.y};
+    vec2 const RMu = transmittanceLUT_UV_to_RMu(atmosphere, W, H, uv);
+
+    vec3 transmittance = vec3(1.0f);
+    float const radius = RMu.x;
+    float const directionCosine = RMu.y;
+    vec3 const origin{0.0f, radius, 0.0f};
+    vec3 const direction{sqrtf(1.0f - directionCosine * directionCosine), directionCosine, 0.0f};
+
+    float t0 = 0.0f, t1 = 0.0f;
+    if (!raySphereIntersection(origin, direction, atmosphere.atmosphereRadiusMm, t0, t1))
+    {
+        return {1.0f, 1.0f, 1.0f, 1.0f};
+    }
+    float const distanceThroughAtmosphere = t1;
+    float const dt = distanceThroughAtmosphere / (float)SAMPLE_COUNT;
+    for (int i = 0; i < SAMPLE_COUNT; i++)
+    {
+        float const t = distanceThroughAtmosphere * ((float)i + 0.5f) / (float)SAMPLE_COUNT;
+        vec3 const position = origin + t * direction;
+        float const altitude = length(position) - atmosphere.planetRadiusMm;
+        ExtinctionSample const extinctionSample = sampleExtinction(atmosphere, altitude);
+        transmittance *= exp3(-fabsf(dt) * extinctionSample.extinction);
+    }
+    return {transmittance.x, transmittance.y, transmittance.z, 1.0f};
+}
+
+// skyview_LUT.comp:51-89
+void uv_to_azimuthElevation(const Atmosphere& atmosphere, float radius, vec2 uv, float& azimuth, float& elevation)
+{
+    float const sinHorizonZenith = atmosphere.planetRadiusMm / radius;
+    float const horizonZenith = PI - asinf(sinHorizonZenith);
+
+    float const cosineViewLightProjected = (uv.x - 0.5f) * 2.0f;
+    vec2 const lightDirectionProjected = normalize(vec2{-atmosphere.incidentDirectionSun.x, -atmosphere.incidentDirectionSun.z});
+
+    float azimuthSun = asinf(lightDirectionProjected.x);
+    if (lightDirectionProjected.y < 0.0f)
+    {
+        azimuthSun = PI - azimuthSun;
+    }
+    azimuth = acosf(clampf(cosineViewLightProjected, -1.0f, 1.0f)) + azimuthSun;
+
+    float viewZenith;
+    if (uv.y < 0.5f)
+    {
+        float const unnormalized_v = 2.0f * uv.y - 1.0f;
+        float const angleFraction = 1.0f - unnormalized_v * unnormalized_v;
+        viewZenith = angleFraction * horizonZenith;
+    }
+    else
+    {
+        float const unnormalized_v = 2.0f * uv.y - 1.0f;
+        float const angleFraction = unnormalized_v * unnormalized_v;
+        viewZenith = (PI - horizonZenith) * angleFraction + horizonZenith;
+    }
+    elevation = -(viewZenith - PI / 2.0f);
+}
+
+// ----------------------------------------------------------------------------
+// shaders/gbuffer/*.glinl, shaders/shadowmap.glinl
+// ----------------------------------------------------------------------------
+struct GBufferTexel // gbufferFunctions.glinl:1-8
+{
+    vec4 position;
+    vec4 normal;
+    vec4 diffuseColor;
+    vec4 specularColor;
+    vec4 occlusionRoughnessMetallic;
+};
+struct GBufferImages
+{
+    Image diffuse, specular, normal, worldPosition, orm;
+};
+GBufferImages gbuffer_images(const szg_gbuffer& g)
+{
+    return {img(g.diffuse), img(g.specular), img(g.normal), img(g.worldPosition), img(g.occlusionRoughnessMetallic)};
+}
+
+// gbufferFunctions.glinl:10-20
+GBufferTexel sampleGBuffer(const GBufferImages& g, vec2 uv)
+{
+    GBufferTexel texel;
+    int x, y;
+    nearest_edge(g.diffuse, uv, x, y);
+    texel.diffuseColor = texel_rgba16f(g.diffuse, x, y);
+    nearest_edge(g.specular, uv, x, y);
+    texel.specularColor = texel_rgba16f(g.specular, x, y);
+    nearest_edge(g.normal, uv, x, y);
+    texel.normal = texel_rgba16f(g.normal, x, y);
+    nearest_edge(g.worldPosition, uv, x, y);
+    texel.position = texel_rgba32f(g.worldPosition, x, y);
+    nearest_edge(g.orm, uv, x, y);
+    texel.occlusionRoughnessMetallic = texel_rgba16f(g.orm, x, y);
+    return texel;
+}
+
+struct PBRTexel // pbr.glinl:1-10
+{
+    vec3 position;
+    vec3 normal;
+    vec3 subscatteringColor;
+    vec3 normalReflectance;
+    float occlusion;
+    float specularPower;
+    float metallic;
+};
+
+inline float max3(vec3 rgb) { return fmaxf(fmaxf(rgb.x, rgb.y), rgb.z); } // pbrFunctions.glinl:1
+
+// pbrFunctions.glinl:3-20 (Q6: 0/0 for black specular is kept)
+PBRTexel convertPBRProperties(const GBufferTexel& gbuffer)
+{
+    float const specularPower = 160.0f;
+    vec3 const specularRGB{gbuffer.specularColor.x, gbuffer.specularColor.y, gbuffer.specularColor.z};
+    vec3 const dialectricReflectence = vec3(0.04f);
+    vec3 const metallicReflectence = vec3(0.5f) * specularRGB / max3(specularRGB);
+    float const metallic = gbuffer.occlusionRoughnessMetallic.z;
+    PBRTexel t;
+    t.position = {gbuffer.position.x, gbuffer.position.y, gbuffer.position.z};
+    t.normal = {gbuffer.normal.x, gbuffer.normal.y, gbuffer.normal.z};
+    t.subscatteringColor = {gbuffer.diffuseColor.x, gbuffer.diffuseColor.y, gbuffer.diffuseColor.z};
+    t.normalReflectance = mix(dialectricReflectence, metallicReflectence, metallic);
+    t.occlusion = gbuffer.occlusionRoughnessMetallic.x;
+    t.specularPower = powf(specularPower, 1.0f - gbuffer.occlusionRoughnessMetallic.y);
+    t.metallic = metallic;
+    return t;
+}
+
+// pbrFunctions.glinl:22-32
+vec3 computeFresnel(const PBRTexel& material, vec3 lightOutgoing, vec3 viewOutgoing)
+{
+    vec3 const halfwayDirection = normalize(lightOutgoing + viewOutgoing);
+    float const p = powf(1.0f - clampf(dot(halfwayDirection, lightOutgoing), 0.0f, 1.0f), 5.0f);
+    return material.normalReflectance + (vec3(1.0f) - material.normalReflectance) * p;
+}
+// pbrFunctions.glinl:34-39
+vec3 diffuseBRDF(const PBRTexel& material, vec3) { return material.subscatteringColor / 3.14159265359f; }
+// pbrFunctions.glinl:41-52
+vec3 specularBRDF(const PBRTexel& material, vec3 lightOutgoing, vec3 viewOutgoing)
+{
+    vec3 const halfwayDirection = normalize(lightOutgoing + viewOutgoing);
+    float const specularPower = material.specularPower;
+    float const microfacetDistribution = powf(clampf(dot(halfwayDirection, material.normal), 0.0f, 1.0f), specularPower);
+    float const normalizationTerm = (specularPower + 2.0f) / 8.0f;
+    return vec3(normalizationTerm * microfacetDistribution);
+}
+
+// shadowmap.glinl:2-7 (Q13: column-major literal)
+const mat4 TO_TEX_COORD_MAT = {{0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.5f, 0.5f, 0.0f, 1.0f}};
+
+struct ShadowFrame // shadowmap.glinl:10-15
+{
+    vec4 coord;
+    float dx;
+    float dy;
+};
+
+// shadowmap.glinl:17-30
+ShadowFrame computeShadowFrame(const mat4& lightProjView, vec3 position, vec3 normal)
+{
+    mat4 const shadowMatrix = TO_TEX_COORD_MAT * lightProjView;
+    vec4 shadowCoord = shadowMatrix * vec4{position.x, position.y, position.z, 1.0f};
+    float const w = shadowCoord.w;
+    shadowCoord = {shadowCoord.x / w, shadowCoord.y / w, shadowCoord.z / w, shadowCoord.w / w};
+    vec4 const projectedNormal = shadowMatrix * vec4{normal.x, normal.y, normal.z, 0.0f};
+    float const dx = sqrtf(1.0f - clampf(projectedNormal.x * projectedNormal.x, 0.0f, 1.0f));
+    float const dy = sqrtf(1.0f - clampf(projectedNormal.y * projectedNormal.y, 0.0f, 1.0f));
+    return {shadowCoord, dx, dy};
+}
+
+// shadowmap.glinl:32-64. A NULL map = unbound slot = factor 1.0.
+float sampleShadowMap(const szg_image* map, const ShadowFrame& shadow)
+{
+    if (map == nullptr || map->data == nullptr)
+    {
+        return 1.0f;
+    }
+    Image const im = img(*map);
+    float const fragmentDepth = shadow.coord.z;
+    float const dx = 1.5f * shadow.dx / (float)(int)im.width;
+    float const dy = 1.5f * shadow.dy / (float)(int)im.height;
+    float summedDistance = 0.0f;
+    int const SAMPLE_RANGE = 2;
+    int const SAMPLE_COUNT = (2 * SAMPLE_RANGE + 1) * (2 * SAMPLE_RANGE + 1);
+    for (int y = -SAMPLE_RANGE; y <= SAMPLE_RANGE; y++)
+    {
+        for (int x = -SAMPLE_RANGE; x <= SAMPLE_RANGE; x++)
+        {
+            vec2 const offsetShadowCoord = vec2{shadow.coord.x, shadow.coord.y} + vec2{(float)x * dx, (float)y * dy};
+            float const occluderDepth = sample_depth_border(im, offsetShadowCoord);
+            if (occluderDepth > 0.0f && occluderDepth > fragmentDepth)
+            {
+                summedDistance += 1.0f;
+            }
+        }
+    }
+    return 1.0f - summedDistance / (float)SAMPLE_COUNT;
+}
+
+const szg_image* shadow_map_at(const szg_shadowmaps* maps, uint32_t index)
+{
+    if (maps == nullptr || maps->maps == nullptr || index >= maps->count)
+    {
+        return nullptr;
+    }
+    return &maps->maps[index];
+}
+
+// ----------------------------------------------------------------------------
+// deferred/lights.comp:59-108
+// ----------------------------------------------------------------------------
+struct IncomingLight
+{
+    vec3 lightDirectionUnit;
+    vec3 lightSpectralFactor;
+};
+
+// lights.comp:65-71
+IncomingLight computeIncomingLight(const szg_directional_light_packed& light, const ShadowFrame& shadow, const szg_image* map)
+{
+    vec3 const lightDirectionUnit = normalize(-v3(light.forward));
+    vec3 const lightSpectralFactor = v3(light.color) * light.strength * sampleShadowMap(map, shadow);
+    return {lightDirectionUnit, lightSpectralFactor};
+}
+
+// lights.comp:73-91
+IncomingLight computeIncomingLight(const szg_spot_light_packed& light, vec3 worldPosition, const ShadowFrame& shadow,
+                                   const szg_image* map)
+{
+    vec3 const lightDirectionUnit = normalize(-v3(light.forward));
+    float const lightNormalizedDistance = distance(v3(light.position), worldPosition) / light.falloffDistance;
+    float const lightFalloff = light.falloffFactor * lightNormalizedDistance * lightNormalizedDistance;
+    float const distanceUV = clampf(distance(vec2{shadow.coord.x, shadow.coord.y}, vec2{0.5f, 0.5f}) / 0.5f, 0.0f, 1.0f);
+    float const edgeSoftening = 1.0f - distanceUV * distanceUV;
+    vec3 const lightSpectralFactor =
+        v3(light.color) * light.strength / lightFalloff * edgeSoftening * sampleShadowMap(map, shadow);
+    return {lightDirectionUnit, lightSpectralFactor};
+}
+
+// lights.comp:93-108
+vec3 computeLightContribution(const IncomingLight& light, const PBRTexel& material, vec3 viewDirection)
+{
+    vec3 const lightDirection = light.lightDirectionUnit;
+    vec3 const diffuseContribution = diffuseBRDF(material, lightDirection);
+    vec3 const specularContribution = specularBRDF(material, lightDirection, viewDirection);
+    vec3 const fresnel = computeFresnel(material, lightDirection, viewDirection);
+    return material.occlusion * mix(diffuseContribution, specularContribution, fresnel) * light.lightSpectralFactor *
+           clampf(dot(material.normal, lightDirection), 0.0f, 1.0f);
+}
+
+// ----------------------------------------------------------------------------
+// atmosphere/camera.comp:70-301
+// ----------------------------------------------------------------------------
+struct CompositeContext
+{
+    Atmosphere atmosphere;
+    TransmittanceLUT transmittance_LUT;
+    Image skyview_LUT;
+};
+
+// camera.comp:70-121
+vec3 sampleMap_Direction(const CompositeContext& c, vec3 position, vec3 direction)
+{
+    const Atmosphere& atmosphere = c.atmosphere;
+    vec3 const normalized = normalize(direction);
+    float const sinHorizonZenith = atmosphere.planetRadiusMm / length(position);
+    float const horizonZenith = PI - asinf(sinHorizonZenith);
+    float const cosViewZenith = normalized.y;
+    float const cosHorizonZenith = -safeSqrt(1.0f - sinHorizonZenith * sinHorizonZenith);
+    float const viewZenith = acosf(normalized.y);
+    float u, v;
+    if (cosViewZenith > cosHorizonZenith)
+    {
+        float const angleFraction = viewZenith / horizonZenith;
+        v = (1.0f - sqrtf(1.0f - angleFraction)) * 0.5f;
+    }
+    else
+    {
+        float const angleFraction = (viewZenith - horizonZenith) / (PI - horizonZenith);
+        v = sqrtf(angleFraction) * 0.5f + 0.5f;
+    }
+    {
+        vec2 const projectedLightDirection = normalize(vec2{-atmosphere.incidentDirectionSun.x, -atmosphere.incidentDirectionSun.z});
+        vec2 const projectedViewDirection = normalize(vec2{direction.x, direction.z});
+        u = clampf(dot(projectedLightDirection, projectedViewDirection), -1.0f, 1.0f) * 0.5f + 0.5f;
+    }
+    return sample_linear_rgb(c.skyview_LUT, vec2{u, v});
+}
+
+// camera.comp:123-140 (Q4)
+vec3 sampleSunDisk(const CompositeContext& c, vec3 position, vec3 direction)
+{
+    const Atmosphere& atmosphere = c.atmosphere;
+    vec3 const directionToSun = -atmosphere.incidentDirectionSun;
+    float const cosDirectionSun = dot(direction, directionToSun) / (length(direction) * length(directionToSun));
+    float const sinSunRadius = atmosphere.sunAngularRadius;
+    float const sinDirectionSun = safeSqrt(1.0f - cosDirectionSun * cosDirectionSun);
+    vec3 const transmittanceToSun = sampleTransmittanceLUT_Ray(c.transmittance_LUT, atmosphere, position, direction);
+    if (cosDirectionSun < 0.0f)
+    {
+        return vec3(0.0f);
+    }
+    return transmittanceToSun * (1.0f - smoothstep(0.2f * sinSunRadius, sinSunRadius, sinDirectionSun));
+}
+
+// camera.comp:142-173 (Q3: returns at line 147)
+float computeFractionOfSunVisible(const Atmosphere& atmosphere, float radius)
+{
+    float const sinHorizonZenith = atmosphere.planetRadiusMm / radius;
+    return sinHorizonZenith;
+}
+
+// camera.comp:175-192
+bool raycastDistanceToGround(const Atmosphere& atmosphere, vec3 origin, vec3 direction, float& distanceToGround)
+{
+    float planet_t0 = 0.0f, planet_t1 = 0.0f;
+    bool const hitPlanet =
+        raySphereIntersection(origin, direction, atmosphere.planetRadiusMm, planet_t0, planet_t1) && planet_t0 > 0.0f;
+    if (!hitPlanet)
+    {
+        return false;
+    }
+    distanceToGround = planet_t0;
+    return true;
+}
+
+// camera.comp:194-201
+bool raycastHitTestPlanet(const Atmosphere& atmosphere, vec3 origin, vec3 direction)
+{
+    float planet_t0 = 0.0f, planet_t1 = 0.0f;
+    return raySphereIntersection(origin, direction, atmosphere.planetRadiusMm, planet_t0, planet_t1) && planet_t0 > 0.0f;
+}
+
+// camera.comp:203-235 (Q12)
+vec3 sampleGround(const CompositeContext& c, vec3 origin, vec3 direction, float distanceToGround)
+{
+    const Atmosphere& atmosphere = c.atmosphere;
+    vec3 const surfacePosition = origin + distanceToGround * direction;
+    vec3 const surfaceNormal = normalize(surfacePosition);
+    vec3 const lightDirection = -atmosphere.incidentDirectionSun;
+    vec3 const viewDirection = -direction;
+    vec3 const halfwayDirection = normalize(lightDirection + viewDirection);
+    float const specularPower = 160.0f;
+    float const microfacetAttenuation = powf(clampf(dot(halfwayDirection, surfaceNormal), 0.0f, 1.0f), specularPower);
+    float const normalizationTerm = (specularPower + 2.0f) / 8.0f;
+    vec3 const specular = vec3(normalizationTerm * microfacetAttenuation);
+    vec3 const diffuse = vec3(0.4f) / PI;
+    vec3 const fresnel = vec3(0.04f) + (vec3(1.0f) - vec3(0.04f)) *
+                                           powf(1.0f - clampf(dot(halfwayDirection, lightDirection), 0.0f, 1.0f), 5.0f);
+    vec3 const albedo = mix(diffuse, specular, fresnel);
+    vec3 const transmittanceToSun = sampleTransmittanceLUT_Ray(c.transmittance_LUT, atmosphere, surfacePosition, lightDirection);
+    vec3 const surfaceLuminance = transmittanceToSun * albedo * clampf(dot(surfaceNormal, lightDirection), 0.0f, 1.0f);
+    vec3 const transmittanceToSurface = sampleTransmittanceLUT_Segment(c.transmittance_LUT, atmosphere, origin, surfacePosition);
+    vec3 const aerielPerspectiveLuminance =
+        computeLuminanceScatteringIntegral(atmosphere, c.transmittance_LUT, origin, direction, distanceToGround);
+    return surfaceLuminance * transmittanceToSurface + aerielPerspectiveLuminance;
+}
+
+// camera.comp:237-278
+vec3 computeGeometryLuminanceTransfer(const CompositeContext& c, vec3 origin, vec3 direction, const PBRTexel& material,
+                                      float shadowFactor)
+{
+    const Atmosphere& atmosphere = c.atmosphere;
+    vec3 const surfacePosition = material.position;
+    vec3 const transmittanceToSurface = sampleTransmittanceLUT_Segment(c.transmittance_LUT, atmosphere, origin, surfacePosition);
+    vec3 const lightDirection = normalize(-atmosphere.incidentDirectionSun);
+    vec3 const viewDirection = normalize(-direction);
+    bool const surfaceShadowedByPlanet = raycastHitTestPlanet(atmosphere, surfacePosition, lightDirection);
+    vec3 const diffuseContribution = diffuseBRDF(material, lightDirection);
+    vec3 const specularContribution = specularBRDF(material, lightDirection, viewDirection);
+    vec3 const fresnel = computeFresnel(material, lightDirection, viewDirection);
+    vec3 const transmittanceToSun = sampleTransmittanceLUT_Ray(c.transmittance_LUT, atmosphere, surfacePosition, lightDirection);
+    float const fractionOfSunVisible = computeFractionOfSunVisible(atmosphere, length(material.position));
+    // left-to-right product, as written in camera.comp:268-271
+    float const scalar = shadowFactor * fractionOfSunVisible * (surfaceShadowedByPlanet ? 0.0f : 1.0f);
+    vec3 const surfaceTransfer = scalar * transmittanceToSun * transmittanceToSurface * material.occlusion *
+                                 mix(diffuseContribution, specularContribution, fresnel) *
+                                 clampf(dot(material.normal, lightDirection), 0.0f, 1.0f);
+    float const distanceToGround = length(surfacePosition - origin);
+    vec3 const aerialPerspectiveLuminance =
+        computeLuminanceScatteringIntegral(atmosphere, c.transmittance_LUT, origin, direction, distanceToGround);
+    return surfaceTransfer + aerialPerspectiveLuminance;
+}
+
+// camera.comp:280-284
+vec3 reflectDirection(vec3 normal, vec3 outgoingDirection)
+{
+    vec3 const parallel = dot(normal, outgoingDirection) * normal;
+    return 2.0f * parallel - outgoingDirection;
+}
+
+// camera.comp:286-301
+vec3 sampleEnvironmentLuminanceTransfer(const CompositeContext& c, vec3 position, vec3 direction, float sunShadowFactor)
+{
+    float distanceToGround = 0.0f;
+    if (raycastDistanceToGround(c.atmosphere, position, direction, distanceToGround))
+    {
+        return sampleGround(c, position, direction, distanceToGround);
+    }
+    return sampleMap_Direction(c, position, direction) + sampleSunDisk(c, position, direction) * sunShadowFactor;
+}
+
+inline uint32_t global_row(const szg_rowtile* tile, uint32_t local)
+{
+    if (tile == nullptr || tile->nranks <= 1)
+    {
+        return local;
+    }
+    return ((local / tile->block_rows) * tile->nranks + tile->rank) * tile->block_rows + local % tile->block_rows;
+}
+inline uint32_t local_rows(const szg_rowtile* tile, uint32_t height)
+{
+    if (tile == nullptr || tile->nranks <= 1)
+    {
+        return height;
+    }
+    return tile->local_rows;
+}
+
+void store_debug(const szg_image& dbg, uint32_t x, uint32_t y, vec3 rgb, float a)
+{
+    if (dbg.data == nullptr)
+    {
+        return;
+    }
+    float* p = (float*)((uint8_t*)dbg.data + (size_t)y * dbg.pitch_bytes) + (size_t)x * 4;
+    p[0] = rgb.x;
+    p[1] = rgb.y;
+    p[2] = rgb.z;
+    p[3] = a;
+}
+void store_color(const szg_image& col, uint32_t x, uint32_t y, vec3 rgb, float a)
+{
+    uint16_t* p = (uint16_t*)((uint8_t*)col.data + (size_t)y * col.pitch_bytes) + (size_t)x * 4;
+    p[0] = unorm16_store(rgb.x);
+    p[1] = unorm16_store(rgb.y);
+    p[2] = unorm16_store(rgb.z);
+    p[3] = unorm16_store(a);
+}
+vec4 load_color(const szg_image& col, uint32_t x, uint32_t y)
+{
+    const uint16_t* p = (const uint16_t*)((const uint8_t*)col.data + (size_t)y * col.pitch_bytes) + (size_t)x * 4;
+    return {unorm16_load(p[0]), unorm16_load(p[1]), unorm16_load(p[2]), unorm16_load(p[3])};
+}
+
+} // namespace
+
+// =============================================================================
+// C entry points (all pointers are HOST memory)
+// =============================================================================
+extern "C" {
+
+int oracle_abi_version(void) { return SZG_ABI_VERSION; }
+
+// transmittance_LUT.comp:55-106. out: RGBA32F, width*height*4 floats, row-major.
+void oracle_transmittance_lut(const szg_atmosphere_packed* atmospheres, uint32_t atmosphereIndex, uint32_t width,
+                              uint32_t height, float* out, int threads)
+{
+    Atmosphere const atmosphere = load(atmospheres[atmosphereIndex]);
+    parallel_rows(height, threads, [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t y = r0; y < r1; y++)
+        {
+            for (uint32_t x = 0; x < width; x++)
+            {
+                vec4 const t = transmittance_texel(atmosphere, (int)width, (int)height, (int)x, (int)y);
+                float* p = out + ((size_t)y * width + x) * 4;
+                p[0] = t.x;
+                p[1] = t.y;
+                p[2] = t.z;
+                p[3] = t.w;
+            }
+        }
+    });
+}
+
+// Single texel of the above (for anchors in tests).
+void oracle_transmittance_texel(const szg_atmosphere_packed* atmosphere, uint32_t width, uint32_t height, uint32_t x,
+                                uint32_t y, float out[4])
+{
+    vec4 const t = transmittance_texel(load(*atmosphere), (int)width, (int)height, (int)x, (int)y);
+    out[0] = t.x;
+    out[1] = t.y;
+    out[2] = t.z;
+    out[3] = t.w;
+}
+
+// common.glinl:40-66 / :69-102 exposed for the round-trip property test.
+void oracle_rmu_to_uv(const szg_atmosphere_packed* atmosphere, uint32_t lutWidth, uint32_t lutHeight, float radius, float mu,
+                      float out_uv[2])
+{
+    TransmittanceLUT lut{{nullptr, lutWidth, lutHeight, 0}, (int)lutWidth, (int)lutHeight};
+    vec2 const uv = transmittanceLUT_RMu_to_UV(load(*atmosphere), lut, radius, mu);
+    out_uv[0] = uv.x;
+    out_uv[1] = uv.y;
+}
+void oracle_uv_to_rmu(const szg_atmosphere_packed* atmosphere, uint32_t lutWidth, uint32_t lutHeight, float u, float v,
+                      float out_rmu[2])
+{
+    vec2 const rmu = transmittanceLUT_UV_to_RMu(load(*atmosphere), (int)lutWidth, (int)lutHeight, vec2{u, v});
+    out_rmu[0] = rmu.x;
+    out_rmu[1] = rmu.y;
+}
+
+// common.glinl:364-424 exposed for the froxel / property tests.
+void oracle_scattering_integral(const szg_atmosphere_packed* atmosphere, const float* transmittanceLUT, uint32_t tWidth,
+                                uint32_t tHeight, const float origin[3], const float direction[3], float sampleDistance,
+                                float out_rgb[3])
+{
+    TransmittanceLUT const lut{{(const uint8_t*)transmittanceLUT, tWidth, tHeight, tWidth * 16u}, (int)tWidth, (int)tHeight};
+    vec3 const l = computeLuminanceScatteringIntegral(load(*atmosphere), lut, v3(origin), v3(direction), sampleDistance);
+    out_rgb[0] = l.x;
+    out_rgb[1] = l.y;
+    out_rgb[2] = l.z;
+}
+
+// skyview_LUT.comp:91-128. transmittanceLUT: RGBA32F tWidth*tHeight; out: RGBA32F width*height.
+void oracle_skyview_lut(const szg_atmosphere_packed* atmospheres, uint32_t atmosphereIndex, const szg_camera_packed* cameras,
+                        uint32_t cameraIndex, const float* transmittanceLUT, uint32_t tWidth, uint32_t tHeight,
+                        uint32_t width, uint32_t height, float* out, uint32_t row_begin, uint32_t row_end, int threads)
+{
+    Atmosphere const atmosphere = load(atmospheres[atmosphereIndex]);
+    szg_camera_packed const& camera = cameras[cameraIndex];
+    TransmittanceLUT const lut{{(const uint8_t*)transmittanceLUT, tWidth, tHeight, tWidth * 16u}, (int)tWidth, (int)tHeight};
+    row_end = std::min(row_end, height);
+    if (row_begin >= row_end)
+    {
+        return;
+    }
+    parallel_rows(row_end - row_begin, threads, [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t yy = r0; yy < r1; yy++)
+        {
+            uint32_t const y = row_begin + yy;
+            for (uint32_t x = 0; x < width; x++)
+            {
+                vec2 const size{(float)width, (float)height};
+                vec2 const uv{((float)x + 0.5f) / size.x, ((float)y + 0.5f) / size.y};
+
+                vec3 origin = v3(camera.position) / METERS_PER_MM;
+                origin.y *= -1.0f;
+                origin.y += atmosphere.planetRadiusMm;
+
+                float azimuth, elevation;
+                uv_to_azimuthElevation(atmosphere, length(origin), uv, azimuth, elevation);
+                vec3 const direction =
+                    normalize(vec3{sinf(azimuth) * cosf(elevation), sinf(elevation), cosf(azimuth) * cosf(elevation)});
+
+                float distanceThroughAtmosphere;
+                raycastAtmosphere(atmosphere, origin, direction, distanceThroughAtmosphere);
+                vec3 const luminance =
+                    computeLuminanceScatteringIntegral(atmosphere, lut, origin, direction, distanceThroughAtmosphere);
+                float* p = out + ((size_t)y * width + x) * 4;
+                p[0] = luminance.x;
+                p[1] = luminance.y;
+                p[2] = luminance.z;
+                p[3] = 1.0f;
+            }
+        }
+    });
+}
+
+// deferred/lights.comp:110-164 preceded by the clear of the scene colour to
+// opaque black (deferred.cpp:715-717) for every pixel of the draw rect.
+void oracle_lights(const szg_scene_texture* scene, szg_rect drawRect, const szg_rowtile* tile, const szg_gbuffer* gbuffer,
+                   const szg_shadowmaps* shadowMaps, const szg_camera_packed* cameras, uint32_t cameraIndex,
+                   const szg_directional_light_packed* directionalLights, uint32_t directionalLightCount,
+                   uint32_t directionalLightSkipCount, const szg_spot_light_packed* spotLights, uint32_t spotLightCount,
+                   int threads)
+{
+    GBufferImages const g = gbuffer_images(*gbuffer);
+    vec2 const gbufferExtent{(float)gbuffer->diffuse.width, (float)gbuffer->diffuse.height};
+    szg_camera_packed const& camera = cameras[cameraIndex];
+    uint32_t const rows = local_rows(tile, drawRect.height);
+
+    parallel_rows(rows, threads, [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t y = r0; y < r1; y++)
+        {
+            for (uint32_t x = 0; x < drawRect.width; x++)
+            {
+                // recordClearColorImage(..., COLOR_BLACK_OPAQUE), deferred.cpp:715-717
+                store_color(scene->color, x, y, vec3(0.0f), 1.0f);
+                store_debug(scene->debug_color, x, y, vec3(0.0f), 1.0f);
+
+                vec2 const gbufferUV{((float)x + 0.5f) / gbufferExtent.x, ((float)y + 0.5f) / gbufferExtent.y};
+                GBufferTexel const gbufferTexel = sampleGBuffer(g, gbufferUV);
+                if (gbufferTexel.diffuseColor.w < 1.0f)
+                {
+                    continue;
+                }
+                PBRTexel const material = convertPBRProperties(gbufferTexel);
+                vec3 const viewDirection = normalize(v3(camera.position) - material.position);
+                vec3 lightContribution = vec3(0.0f);
+                uint32_t shadowMapIndex = directionalLightSkipCount;
+                for (int i = (int)directionalLightSkipCount; i < (int)directionalLightCount; i++)
+                {
+                    szg_directional_light_packed const& light = directionalLights[i];
+                    ShadowFrame const shadow =
+                        computeShadowFrame(load(light.projection) * load(light.view), material.position, material.normal);
+                    IncomingLight const incoming = computeIncomingLight(light, shadow, shadow_map_at(shadowMaps, shadowMapIndex));
+                    lightContribution += computeLightContribution(incoming, material, viewDirection);
+                    shadowMapIndex += 1;
+                }
+                for (int i = 0; i < (int)spotLightCount; i++)
+                {
+                    szg_spot_light_packed const& light = spotLights[i];
+                    ShadowFrame const shadow =
+                        computeShadowFrame(load(light.projection) * load(light.view), material.position, material.normal);
+                    IncomingLight const incoming =
+                        computeIncomingLight(light, material.position, shadow, shadow_map_at(shadowMaps, shadowMapIndex));
+                    lightContribution += computeLightContribution(incoming, material, viewDirection);
+                    shadowMapIndex += 1;
+                }
+                store_color(scene->color, x, y, lightContribution, 1.0f);
+                store_debug(scene->debug_color, x, y, lightContribution, 1.0f);
+            }
+        }
+    });
+}
+
+// atmosphere/camera.comp:303-395
+void oracle_composite(const szg_scene_texture* scene, szg_rect drawRect, const szg_rowtile* tile, const szg_gbuffer* gbuffer,
+                      const szg_shadowmaps* shadowMaps, const szg_atmosphere_packed* atmospheres, uint32_t atmosphereIndex,
+                      const szg_camera_packed* cameras, uint32_t cameraIndex,
+                      const szg_directional_light_packed* directionalLights, uint32_t sunLightIndex,
+                      const float* transmittanceLUT, uint32_t tWidth, uint32_t tHeight, const float* skyviewLUT,
+                      uint32_t sWidth, uint32_t sHeight, int threads)
+{
+    CompositeContext c;
+    c.atmosphere = load(atmospheres[atmosphereIndex]);
+    c.transmittance_LUT = {{(const uint8_t*)transmittanceLUT, tWidth, tHeight, tWidth * 16u}, (int)tWidth, (int)tHeight};
+    c.skyview_LUT = {(const uint8_t*)skyviewLUT, sWidth, sHeight, sWidth * 16u};
+    const Atmosphere& atmosphere = c.atmosphere;
+    szg_camera_packed const& camera = cameras[cameraIndex];
+    GBufferImages const g = gbuffer_images(*gbuffer);
+    Image const depthImage = img(scene->depth);
+    vec2 const size{(float)scene->color.width, (float)scene->color.height};
+    uint32_t const rows = local_rows(tile, drawRect.height);
+    mat4 const inverseProjection = load(camera.inverseProjection);
+    mat4 const rotation = load(camera.rotation);
+
+    parallel_rows(rows, threads, [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t y = r0; y < r1; y++)
+        {
+            uint32_t const gy = global_row(tile, y);
+            for (uint32_t x = 0; x < drawRect.width; x++)
+            {
+                vec2 const uvFull{((float)x + 0.5f) / size.x, ((float)y + 0.5f) / size.y};
+                float const sceneDepth = sample_depth_border(depthImage, uvFull);
+
+                vec3 position = v3(camera.position) / METERS_PER_MM;
+                position.y *= -1.0f;
+                position.y += atmosphere.planetRadiusMm;
+
+                // Q5: no +0.5; global pixel coordinates over the full draw extent
+                vec2 const clipSpaceUV{((float)x / (float)drawRect.width - 0.5f) * 2.0f,
+                                       ((float)gy / (float)drawRect.height - 0.5f) * 2.0f};
+                float const nearPlaneDepth = 1.0f;
+                vec4 const directionViewSpace = inverseProjection * vec4{clipSpaceUV.x, clipSpaceUV.y, nearPlaneDepth, 1.0f};
+                vec4 const rotated = rotation * directionViewSpace;
+                vec3 direction = normalize(vec3{rotated.x, rotated.y, rotated.z});
+                direction.y *= -1.0f;
+
+                vec3 sunIlluminanceToSkyLuminanceTransfer = vec3(0.0f);
+                vec3 surfaceLuminance = vec3(0.0f);
+
+                vec2 const uvGBuffer{((float)x + 0.5f) / (float)gbuffer->diffuse.width,
+                                     ((float)y + 0.5f) / (float)gbuffer->diffuse.height};
+                PBRTexel material = convertPBRProperties(sampleGBuffer(g, uvGBuffer));
+
+                szg_directional_light_packed const& sunDirectionalLight = directionalLights[sunLightIndex];
+
+                if (sceneDepth == 0.0f || material.position.y > 0.0f)
+                {
+                    float const shadowFactor = 1.0f;
+                    sunIlluminanceToSkyLuminanceTransfer +=
+                        sampleEnvironmentLuminanceTransfer(c, position, direction, shadowFactor);
+                }
+                else
+                {
+                    vec4 const prior = load_color(scene->color, x, y);
+                    surfaceLuminance = {prior.x, prior.y, prior.z};
+
+                    ShadowFrame const shadowframe =
+                        computeShadowFrame(load(sunDirectionalLight.projection) * load(sunDirectionalLight.view),
+                                           material.position, material.normal);
+                    // Q11: indexed with sunLightIndex
+                    float const surfaceSunShadowFactor = sampleShadowMap(shadow_map_at(shadowMaps, sunLightIndex), shadowframe);
+
+                    // Q18: flipped to atmosphere space after the shadow frame
+                    material.normal.y *= -1.0f;
+                    material.position.y *= -1.0f;
+                    material.position = material.position / 1000000.0f;
+                    material.position.y += atmosphere.planetRadiusMm;
+
+                    sunIlluminanceToSkyLuminanceTransfer +=
+                        computeGeometryLuminanceTransfer(c, position, direction, material, surfaceSunShadowFactor);
+
+                    vec3 const transmittanceToSurface =
+                        sampleTransmittanceLUT_Segment(c.transmittance_LUT, atmosphere, position, material.position);
+                    vec3 const reflectionDirection = reflectDirection(material.normal, -direction);
+                    sunIlluminanceToSkyLuminanceTransfer +=
+                        transmittanceToSurface * material.metallic * computeFresnel(material, -direction, reflectionDirection) *
+                        sampleEnvironmentLuminanceTransfer(c, material.position, reflectionDirection, surfaceSunShadowFactor);
+                }
+
+                vec3 const luminance = sunIlluminanceToSkyLuminanceTransfer * atmosphere.sunIntensitySpectrum;
+                vec3 const color = pow3(luminance * 10.0f + surfaceLuminance, 1.2f);
+                store_color(scene->color, x, y, color, 1.0f);
+                store_debug(scene->debug_color, x, y, color, 1.0f);
+            }
+        }
+    });
+}
+
+// Synthetic G-buffer fill (stands in for deferred/offscreen.vert:41-56 +
+// offscreen.frag:61-79 + raster state deferred.cpp:342-392, :546-549): one
+// primary ray per pixel centre against an axis-aligned ground rectangle and
+// axis-aligned boxes; nearest hit wins (reverse-Z GREATER depth test).
+// Writes the five G-buffer planes and the D32F depth with the reference's
+// output conventions: position.w = 1, normal.w = 0, diffuse = specular =
+// albedo with a = 1, ORM a = 1; background all zero, depth 0.
+void oracle_gbuffer_fill(const szg_scene_texture* scene, szg_rect drawRect, const szg_rowtile* tile, const szg_gbuffer* gbuffer,
+                         const szg_camera_packed* cameras, uint32_t cameraIndex, const szg_fill_scene* geometry, int threads)
+{
+    szg_camera_packed const& camera = cameras[cameraIndex];
+    mat4 const inverseProjection = load(camera.inverseProjection);
+    mat4 const rotation = load(camera.rotation);
+    mat4 const projection = load(camera.projection);
+    mat4 const view = load(camera.view);
+    uint32_t const rows = local_rows(tile, drawRect.height);
+    vec3 const origin = v3(camera.position);
+
+    parallel_rows(rows, threads, [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t y = r0; y < r1; y++)
+        {
+            uint32_t const gy = global_row(tile, y);
+            for (uint32_t x = 0; x < drawRect.width; x++)
+            {
+                vec2 const ndc{(((float)x + 0.5f) / (float)drawRect.width - 0.5f) * 2.0f,
+                               (((float)gy + 0.5f) / (float)drawRect.height - 0.5f) * 2.0f};
+                vec4 const dv = inverseProjection * vec4{ndc.x, ndc.y, 1.0f, 1.0f};
+                vec4 const dw = rotation * dv;
+                vec3 const dir = normalize(vec3{dw.x, dw.y, dw.z});
+
+                float best_t = 3.0e38f;
+                vec3 best_n = vec3(0.0f);
+                float best_metallic = 0.0f;
+                float best_roughness = 0.0f;
+                bool hit = false;
+
+                // ground rectangle at y = ground_y, facing up (-y)
+                if (dir.y != 0.0f)
+                {
+                    float const t = (geometry->ground_y - origin.y) / dir.y;
+                    if (t > 0.0f)
+                    {
+                        vec3 const p = origin + t * dir;
+                        if (fabsf(p.x) <= geometry->ground_half_extent && fabsf(p.z) <= geometry->ground_half_extent &&
+                            t < best_t)
+                        {
+                            best_t = t;
+                            best_n = vec3{0.0f, -1.0f, 0.0f};
+                            best_metallic = 0.0f;
+                            best_roughness = geometry->ground_roughness;
+                            hit = true;
+                        }
+                    }
+                }
+                // boxes, slab method
+                for (uint32_t b = 0; b < geometry->box_count; b++)
+                {
+                    szg_fill_box const& box = geometry->boxes[b];
+                    float tmin = -3.0e38f, tmax = 3.0e38f;
+                    int axis_min = 0;
+                    float sign_min = 0.0f;
+                    bool miss = false;
+                    float const o[3] = {origin.x, origin.y, origin.z};
+                    float const d[3] = {dir.x, dir.y, dir.z};
+                    for (int a = 0; a < 3; a++)
+                    {
+                        float const lo = box.center[a] - box.half_extent[a];
+                        float const hi = box.center[a] + box.half_extent[a];
+                        if (d[a] == 0.0f)
+                        {
+                            if (o[a] < lo || o[a] > hi)
+                            {
+                                miss = true;
+                            }
+                            continue;
+                        }
+                        float t0 = (lo - o[a]) / d[a];
+                        float t1 = (hi - o[a]) / d[a];
+                        float s = -1.0f; // entering through the low face: outward normal is -axis
+                        if (t0 > t1)
+                        {
+                            float const tmp = t0;
+                            t0 = t1;
+                            t1 = tmp;
+                            s = 1.0f;
+                        }
+                        if (t0 > tmin)
+                        {
+                            tmin = t0;
+                            axis_min = a;
+                            sign_min = s;
+                        }
+                        if (t1 < tmax)
+                        {
+                            tmax = t1;
+                        }
+                    }
+                    if (miss || tmin > tmax || tmin <= 0.0f)
+                    {
+                        continue;
+                    }
+                    if (tmin < best_t)
+                    {
+                        best_t = tmin;
+                        best_n = vec3{axis_min == 0 ? sign_min : 0.0f, axis_min == 1 ? sign_min : 0.0f,
+                                      axis_min == 2 ? sign_min : 0.0f};
+                        best_metallic = box.metallic;
+                        best_roughness = box.roughness;
+                        hit = true;
+                    }
+                }
+
+                float depth = 0.0f;
+                vec4 pos4{0.0f, 0.0f, 0.0f, 0.0f}, nrm4{0.0f, 0.0f, 0.0f, 0.0f}, dif4{0.0f, 0.0f, 0.0f, 0.0f},
+                    orm4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (hit)
+                {
+                    vec3 const p = origin + best_t * dir;
+                    vec4 const clip = projection * (view * vec4{p.x, p.y, p.z, 1.0f});
+                    depth = clip.z / clip.w;
+                    if (!(depth > 0.0f && depth <= 1.0f))
+                    {
+                        hit = false; // outside the depth range: clipped by the rasteriser
+                        depth = 0.0f;
+                    }
+                    else
+                    {
+                        float const cell = geometry->checker_cell;
+                        float const cx = floorf(p.x / cell), cy = floorf(p.y / cell), cz = floorf(p.z / cell);
+                        // parity of the cell index sum; computed in float to stay exact for |index| < 2^24
+                        float const s = cx + cy + cz;
+                        bool const light = (s - 2.0f * floorf(s * 0.5f)) == 0.0f;
+                        float const grey = light ? (200.0f / 255.0f) : (100.0f / 255.0f);
+                        pos4 = {p.x, p.y, p.z, 1.0f};
+                        nrm4 = {best_n.x, best_n.y, best_n.z, 0.0f};
+                        dif4 = {grey, grey, grey, 1.0f};
+                        orm4 = {1.0f, best_roughness, best_metallic, 1.0f};
+                    }
+                }
+                auto put16 = [&](const szg_image& im, vec4 v) {
+                    uint16_t* q = (uint16_t*)((uint8_t*)im.data + (size_t)y * im.pitch_bytes) + (size_t)x * 4;
+                    q[0] = float_to_half(v.x);
+                    q[1] = float_to_half(v.y);
+                    q[2] = float_to_half(v.z);
+                    q[3] = float_to_half(v.w);
+                };
+                put16(gbuffer->diffuse, dif4);
+                put16(gbuffer->specular, dif4);
+                put16(gbuffer->normal, nrm4);
+                put16(gbuffer->occlusionRoughnessMetallic, orm4);
+                float* pp = (float*)((uint8_t*)gbuffer->worldPosition.data + (size_t)y * gbuffer->worldPosition.pitch_bytes) +
+                            (size_t)x * 4;
+                pp[0] = pos4.x;
+                pp[1] = pos4.y;
+                pp[2] = pos4.z;
+                pp[3] = pos4.w;
+                float* dp = (float*)((uint8_t*)scene->depth.data + (size_t)y * scene->depth.pitch_bytes) + x;
+                *dp = depth;
+            }
+        }
+    });
+}
+
+// fp16 helpers exposed so tests can cross-check them against numpy.float16
+uint16_t oracle_float_to_half(float f) { return float_to_half(f); }
+float oracle_half_to_float(uint16_t h) { return half_to_float(h); }
+uint16_t oracle_unorm16_store(float f) { return unorm16_store(f); }
+
+} // extern "C"

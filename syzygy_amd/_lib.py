@@ -1,0 +1,45 @@
+"""Loader for the C-ABI shared library (syzygy_amd/csrc/libszg_hip.so)."""
+import ctypes
+import os
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class SzgError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code, message):
+        super().__init__(f"szg status {code}: {message}")
+        self.code = code
+
+
+def library_path():
+    return os.path.join(_HERE, "csrc", "libszg_hip.so")
+
+
+def lib():
+    """The bound ctypes library. Fails loudly when it has not been built."""
+    global _LIB
+    if _LIB is None:
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(or `make -C syzygy_amd/csrc`). There is no CPU fallback for this path."
+            )
+        handle = ctypes.CDLL(path)
+        abi.bind(handle, abi.ABI_FUNCTIONS)
+        abi.bind(handle, abi.HOST_FUNCTIONS)
+        if handle.szg_abi_version() != abi.SZG_ABI_VERSION:
+            raise RuntimeError("libszg_hip.so ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def check(status):
+    if status != abi.SZG_OK:
+        raise SzgError(status, lib().szg_last_error().decode("utf-8", "replace"))
+    return status

@@ -1,0 +1,442 @@
+// kernels_deferred.hip — G-buffer fill, light-list prep, deferred lights and the
+// multi-GPU row-tile compose copy, for gfx950.
+//
+//   k_gbuffer_fill : output conventions of deferred/offscreen.frag:61-79 with the
+//                    raster state of renderer/pipelines/deferred.cpp:342-392
+//                    (analytic ray cast instead of the fixed-function rasteriser)
+//   k_light_prep   : per-light invariants of deferred/lights.comp:141-161
+//   k_lights       : deferred/lights.comp:110-164, fused with the clear of the
+//                    scene colour (deferred.cpp:715-717)
+//   k_compose      : HBM-bound row scatter after the RCCL gather
+
+#include "szg_device.hpp"
+#include "szg_launch.hpp"
+
+namespace szg
+{
+namespace
+{
+// 256-thread workgroup = 32x8 pixels; each wave an 8x8 patch.
+SZG_DEV void pixel_of_thread(unsigned& x, unsigned& y)
+{
+    unsigned const tid = threadIdx.x;
+    unsigned const wave = tid >> 6, lane = tid & 63u;
+    x = blockIdx.x * 32u + wave * 8u + (lane & 7u);
+    y = blockIdx.y * 8u + (lane >> 3);
+}
+
+template <typename T> SZG_DEV T* row_ptr(const szg_image& im, unsigned y)
+{
+    return reinterpret_cast<T*>(static_cast<unsigned char*>(im.data) + (size_t)y * im.pitch_bytes);
+}
+} // namespace
+
+struct GBufferPtrs
+{
+    szg_image diffuse, specular, normal, position, orm;
+};
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gbuffer_fill(szg_image depth, GBufferPtrs g, unsigned drawW, unsigned drawH,
+                                                      unsigned localRows, RowMap rm,
+                                                      const szg_camera_packed* __restrict__ cameras, unsigned cameraIndex,
+                                                      float ground_y, float ground_half_extent, float checker_cell,
+                                                      float ground_roughness, const szg_fill_box* __restrict__ boxes,
+                                                      unsigned boxCount)
+{
+    unsigned x, y;
+    pixel_of_thread(x, y);
+    if (x >= drawW || y >= localRows)
+    {
+        return;
+    }
+    unsigned const gy = global_row(rm, y);
+    const szg_camera_packed* cam = cameras + cameraIndex;
+    M4 const inverseProjection = load_m4(cam->inverseProjection);
+    M4 const rotation = load_m4(cam->rotation);
+    V3 const origin = mk3(cam->position[0], cam->position[1], cam->position[2]);
+
+    float const ndcx = (((float)x + 0.5f) / (float)drawW - 0.5f) * 2.0f;
+    float const ndcy = (((float)gy + 0.5f) / (float)drawH - 0.5f) * 2.0f;
+    V4 const dv = mul(inverseProjection, ndcx, ndcy, 1.0f, 1.0f);
+    V4 const dw = mul(rotation, dv.x, dv.y, dv.z, dv.w);
+    V3 const dir = normalize(mk3(dw.x, dw.y, dw.z));
+
+    float best_t = 3.0e38f;
+    V3 best_n = splat(0.0f);
+    float best_metallic = 0.0f, best_roughness = 0.0f;
+    bool hit = false;
+
+    if (dir.y != 0.0f)
+    {
+        float const t = (ground_y - origin.y) / dir.y;
+        if (t > 0.0f)
+        {
+            V3 const p = origin + t * dir;
+            if (fabsf(p.x) <= ground_half_extent && fabsf(p.z) <= ground_half_extent && t < best_t)
+            {
+                best_t = t;
+                best_n = mk3(0.0f, -1.0f, 0.0f);
+                best_metallic = 0.0f;
+                best_roughness = ground_roughness;
+                hit = true;
+            }
+        }
+    }
+    float const o[3] = {origin.x, origin.y, origin.z};
+    float const d[3] = {dir.x, dir.y, dir.z};
+    for (unsigned b = 0; b < boxCount; b++)
+    {
+        szg_fill_box const box = boxes[b];
+        float tmin = -3.0e38f, tmax = 3.0e38f;
+        int axis_min = 0;
+        float sign_min = 0.0f;
+        bool miss = false;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++)
+        {
+            float const lo = box.center[ax] - box.half_extent[ax];
+            float const hi = box.center[ax] + box.half_extent[ax];
+            if (d[ax] == 0.0f)
+            {
+                if (o[ax] < lo || o[ax] > hi)
+                {
+                    miss = true;
+                }
+                continue;
+            }
+            float t0 = (lo - o[ax]) / d[ax];
+            float t1 = (hi - o[ax]) / d[ax];
+            float s = -1.0f;
+            if (t0 > t1)
+            {
+                float const tmp = t0;
+                t0 = t1;
+                t1 = tmp;
+                s = 1.0f;
+            }
+            if (t0 > tmin)
+            {
+                tmin = t0;
+                axis_min = ax;
+                sign_min = s;
+            }
+            if (t1 < tmax)
+            {
+                tmax = t1;
+            }
+        }
+        if (miss || tmin > tmax || tmin <= 0.0f)
+        {
+            continue;
+        }
+        if (tmin < best_t)
+        {
+            best_t = tmin;
+            best_n = mk3(axis_min == 0 ? sign_min : 0.0f, axis_min == 1 ? sign_min : 0.0f, axis_min == 2 ? sign_min : 0.0f);
+            best_metallic = box.metallic;
+            best_roughness = box.roughness;
+            hit = true;
+        }
+    }
+
+    float depthOut = 0.0f;
+    float4 pos4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    uint2 nrm = pack_half4(0.0f, 0.0f, 0.0f, 0.0f), dif = nrm, orm = nrm;
+    if (hit)
+    {
+        V3 const p = origin + best_t * dir;
+        M4 const projection = load_m4(cam->projection);
+        M4 const view = load_m4(cam->view);
+        V4 const pv = mul(view, p.x, p.y, p.z, 1.0f);
+        V4 const clip = mul(projection, pv.x, pv.y, pv.z, pv.w);
+        float const dz = clip.z / clip.w;
+        if (dz > 0.0f && dz <= 1.0f)
+        {
+            depthOut = dz;
+            float const cx = floorf(p.x / checker_cell), cy = floorf(p.y / checker_cell), cz = floorf(p.z / checker_cell);
+            float const s = cx + cy + cz;
+            bool const light = (s - 2.0f * floorf(s * 0.5f)) == 0.0f;
+            float const grey = light ? (200.0f / 255.0f) : (100.0f / 255.0f);
+            pos4 = make_float4(p.x, p.y, p.z, 1.0f);
+            nrm = pack_half4(best_n.x, best_n.y, best_n.z, 0.0f);
+            dif = pack_half4(grey, grey, grey, 1.0f);
+            orm = pack_half4(1.0f, best_roughness, best_metallic, 1.0f);
+        }
+    }
+    row_ptr<uint2>(g.diffuse, y)[x] = dif;
+    row_ptr<uint2>(g.specular, y)[x] = dif;
+    row_ptr<uint2>(g.normal, y)[x] = nrm;
+    row_ptr<uint2>(g.orm, y)[x] = orm;
+    row_ptr<float4>(g.position, y)[x] = pos4;
+    row_ptr<float>(depth, y)[x] = depthOut;
+}
+
+// ---------------------------------------------------------------------------
+// One thread per light. Slot numbering follows lights.comp:138-161: the shadow
+// map index starts at directionalLightSkipCount and runs over the directional
+// lights [skip, count) then the spot lights.
+__global__ void k_light_prep(const szg_directional_light_packed* __restrict__ dirs, unsigned dirCount, unsigned dirSkip,
+                             const szg_spot_light_packed* __restrict__ spots, unsigned spotCount,
+                             const ShadowSlot* __restrict__ slots, unsigned slotCount, LightRec* __restrict__ out)
+{
+    unsigned const i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned const nDir = dirCount > dirSkip ? dirCount - dirSkip : 0u;
+    if (i >= nDir + spotCount)
+    {
+        return;
+    }
+    // shadowmap.glinl:2-7
+    M4 toTex;
+    {
+        float const t[16] = {0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.5f, 0.5f, 0.0f, 1.0f};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+            toTex.m[k] = t[k];
+        }
+    }
+    LightRec r;
+    M4 projection, view;
+    V3 forward, color;
+    float strength;
+    if (i < nDir)
+    {
+        const szg_directional_light_packed* l = dirs + dirSkip + i;
+        projection = load_m4(l->projection);
+        view = load_m4(l->view);
+        forward = mk3(l->forward[0], l->forward[1], l->forward[2]);
+        color = mk3(l->color[0], l->color[1], l->color[2]);
+        strength = l->strength;
+        r.isSpot = 0u;
+        r.falloffFactor = 0.0f;
+        r.falloffDistance = 1.0f;
+        r.position[0] = r.position[1] = r.position[2] = 0.0f;
+    }
+    else
+    {
+        const szg_spot_light_packed* l = spots + (i - nDir);
+        projection = load_m4(l->projection);
+        view = load_m4(l->view);
+        forward = mk3(l->forward[0], l->forward[1], l->forward[2]);
+        color = mk3(l->color[0], l->color[1], l->color[2]);
+        strength = l->strength;
+        r.isSpot = 1u;
+        r.falloffFactor = l->falloffFactor;
+        r.falloffDistance = l->falloffDistance;
+        r.position[0] = l->position[0];
+        r.position[1] = l->position[1];
+        r.position[2] = l->position[2];
+    }
+    // computeShadowFrame(light.projection * light.view, ...): TO_TEX * (projection * view)
+    M4 const shadowMatrix = mul(toTex, mul(projection, view));
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        r.shadowMatrix[k] = shadowMatrix.m[k];
+    }
+    V3 const dirUnit = normalize(-forward);
+    r.dir[0] = dirUnit.x;
+    r.dir[1] = dirUnit.y;
+    r.dir[2] = dirUnit.z;
+    V3 const cs = color * strength;
+    r.colorStrength[0] = cs.x;
+    r.colorStrength[1] = cs.y;
+    r.colorStrength[2] = cs.z;
+    unsigned const slot = dirSkip + i;
+    if (slot < slotCount && slots[slot].map != nullptr)
+    {
+        r.map = slots[slot].map;
+        r.mapWidth = slots[slot].width;
+        r.mapHeight = slots[slot].height;
+        r.mapPitchFloats = slots[slot].pitchFloats;
+    }
+    else
+    {
+        r.map = nullptr;
+        r.mapWidth = r.mapHeight = r.mapPitchFloats = 0u;
+    }
+    r.pad[0] = r.pad[1] = r.pad[2] = 0u;
+    out[i] = r;
+}
+
+// ---------------------------------------------------------------------------
+// deferred/lights.comp:110-164. Light records are wave-uniform: the compiler
+// keeps them in SGPRs via scalar loads. A spot light whose edgeSoftening is
+// exactly 0 contributes exactly 0 (lights.comp:84-88) and is skipped
+// before the BRDF is evaluated.
+__global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug, GBufferPtrs g, unsigned drawW,
+                                                unsigned localRows, const szg_camera_packed* __restrict__ cameras,
+                                                unsigned cameraIndex, const LightRec* __restrict__ lights, unsigned lightCount)
+{
+    unsigned x, y;
+    pixel_of_thread(x, y);
+    if (x >= drawW || y >= localRows)
+    {
+        return;
+    }
+    V4 const diffuse = unpack_half4(row_ptr<const uint2>(g.diffuse, y)[x]);
+    V3 sum = splat(0.0f);
+    // lights.comp:126-129: background texels keep the clear colour (0,0,0,1)
+    if (!(diffuse.w < 1.0f))
+    {
+        V4 const specular = unpack_half4(row_ptr<const uint2>(g.specular, y)[x]);
+        V4 const normal = unpack_half4(row_ptr<const uint2>(g.normal, y)[x]);
+        V4 const orm = unpack_half4(row_ptr<const uint2>(g.orm, y)[x]);
+        float4 const p4 = row_ptr<const float4>(g.position, y)[x];
+        Material const m = convertPBR(V4{p4.x, p4.y, p4.z, p4.w}, normal, diffuse, specular, orm);
+
+        const szg_camera_packed* cam = cameras + cameraIndex;
+        V3 const viewDirection = normalize(mk3(cam->position[0], cam->position[1], cam->position[2]) - m.position);
+
+#pragma unroll 1
+        for (unsigned i = 0; i < lightCount; i++)
+        {
+            const LightRec* __restrict__ L = lights + i;
+            const float* sm = L->shadowMatrix;
+            // shadowMatrix * vec4(position, 1), rows summed left to right
+            float const cx = sm[0] * m.position.x + sm[4] * m.position.y + sm[8] * m.position.z + sm[12] * 1.0f;
+            float const cy = sm[1] * m.position.x + sm[5] * m.position.y + sm[9] * m.position.z + sm[13] * 1.0f;
+            float const cw = sm[3] * m.position.x + sm[7] * m.position.y + sm[11] * m.position.z + sm[15] * 1.0f;
+            float const sx = cx / cw;
+            float const sy = cy / cw;
+
+            float factor = 1.0f; // scalar part of lightSpectralFactor after color*strength
+            bool const isSpot = L->isSpot != 0u;
+            float edgeSoftening = 1.0f;
+            float lightFalloff = 1.0f;
+            if (isSpot)
+            {
+                // lights.comp:80-85
+                float const ddx = sx - 0.5f, ddy = sy - 0.5f;
+                float const distanceUV = clampf(sqrtf(ddx * ddx + ddy * ddy) / 0.5f, 0.0f, 1.0f);
+                edgeSoftening = 1.0f - distanceUV * distanceUV;
+                if (edgeSoftening == 0.0f)
+                {
+                    continue;
+                }
+                V3 const toLight = mk3(L->position[0], L->position[1], L->position[2]) - m.position;
+                float const nd = length(toLight) / L->falloffDistance;
+                lightFalloff = L->falloffFactor * nd * nd;
+            }
+            float shadow = 1.0f;
+            if (L->map != nullptr)
+            {
+                float const cz = sm[2] * m.position.x + sm[6] * m.position.y + sm[10] * m.position.z + sm[14] * 1.0f;
+                float const sz = cz / cw;
+                // projectedNormal = shadowMatrix * vec4(normal, 0)
+                float const nx = sm[0] * m.normal.x + sm[4] * m.normal.y + sm[8] * m.normal.z + sm[12] * 0.0f;
+                float const ny = sm[1] * m.normal.x + sm[5] * m.normal.y + sm[9] * m.normal.z + sm[13] * 0.0f;
+                float const fdx = sqrtf(1.0f - clampf(nx * nx, 0.0f, 1.0f));
+                float const fdy = sqrtf(1.0f - clampf(ny * ny, 0.0f, 1.0f));
+                shadow = sampleShadowMap(L->map, L->mapWidth, L->mapHeight, L->mapPitchFloats, mk3(sx, sy, sz), fdx, fdy);
+            }
+            (void)factor;
+            V3 const cs = mk3(L->colorStrength[0], L->colorStrength[1], L->colorStrength[2]);
+            // lights.comp:68 / :87-88
+            V3 const spectral = isSpot ? (((cs / lightFalloff) * edgeSoftening) * shadow) : (cs * shadow);
+            V3 const lightDir = mk3(L->dir[0], L->dir[1], L->dir[2]);
+            // lights.comp:106-107
+            V3 const contribution =
+                ((m.occlusion * brdfMix(m, lightDir, viewDirection)) * spectral) * clampf(dot(m.normal, lightDir), 0.0f, 1.0f);
+            sum = sum + contribution;
+        }
+    }
+    row_ptr<uint2>(color, y)[x] = pack_unorm16x4(sum.x, sum.y, sum.z, 1.0f);
+    if (debug.data != nullptr)
+    {
+        row_ptr<float4>(debug, y)[x] = make_float4(sum.x, sum.y, sum.z, 1.0f);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Row scatter after the gather: rank r's packed tile holds its rows in local
+// order; local row l of rank r is global row ((l / B) * N + r) * B + l % B.
+// 16 B per lane, fully coalesced both sides.
+__global__ __launch_bounds__(256) void k_compose(const uint4* __restrict__ gathered, size_t tileStrideVec, unsigned nranks,
+                                                 unsigned blockRows, unsigned char* __restrict__ dst, unsigned dstPitch,
+                                                 unsigned rowVecs, unsigned height)
+{
+    unsigned const gy = blockIdx.y;
+    unsigned const blk = gy / blockRows;
+    unsigned const rank = blk % nranks;
+    unsigned const local = (blk / nranks) * blockRows + gy % blockRows;
+    const uint4* src = gathered + (size_t)rank * tileStrideVec + (size_t)local * rowVecs;
+    uint4* out = reinterpret_cast<uint4*>(dst + (size_t)gy * dstPitch);
+    for (unsigned v = blockIdx.x * 256u + threadIdx.x; v < rowVecs; v += gridDim.x * 256u)
+    {
+        out[v] = src[v];
+    }
+    (void)height;
+}
+
+// ---------------------------------------------------------------------------
+static GBufferPtrs gptrs(const szg_gbuffer& g)
+{
+    return GBufferPtrs{g.diffuse, g.specular, g.normal, g.worldPosition, g.occlusionRoughnessMetallic};
+}
+static unsigned local_rows_of(const TileArgs& t, unsigned drawH) { return t.nranks <= 1u ? drawH : t.local_rows; }
+
+hipError_t launch_gbuffer_fill(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
+                               const szg_gbuffer& g, const szg_camera_packed* d_cam, unsigned camIndex, float ground_y,
+                               float ground_half_extent, float checker_cell, float ground_roughness,
+                               const szg_fill_box* d_boxes, unsigned boxCount)
+{
+    unsigned const rows = local_rows_of(tile, drawH);
+    if (rows == 0u || drawW == 0u)
+    {
+        return hipSuccess;
+    }
+    dim3 const grid((drawW + 31u) / 32u, (rows + 7u) / 8u);
+    RowMap const rm{tile.block_rows, tile.rank, tile.nranks};
+    hipLaunchKernelGGL(k_gbuffer_fill, grid, dim3(256), 0, s, scene.depth, gptrs(g), drawW, drawH, rows, rm, d_cam, camIndex,
+                       ground_y, ground_half_extent, checker_cell, ground_roughness, d_boxes, boxCount);
+    return hipGetLastError();
+}
+
+hipError_t launch_light_prep(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount, unsigned dirSkip,
+                             const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_slots,
+                             unsigned slotCount, LightRec* d_out)
+{
+    unsigned const nDir = dirCount > dirSkip ? dirCount - dirSkip : 0u;
+    unsigned const n = nDir + spotCount;
+    if (n == 0u)
+    {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_light_prep, dim3((n + 63u) / 64u), dim3(64), 0, s, d_dir, dirCount, dirSkip, d_spot, spotCount, d_slots,
+                       slotCount, d_out);
+    return hipGetLastError();
+}
+
+hipError_t launch_lights(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
+                         const szg_gbuffer& g, const szg_camera_packed* d_cam, unsigned camIndex, const LightRec* d_lights,
+                         unsigned lightCount)
+{
+    unsigned const rows = local_rows_of(tile, drawH);
+    if (rows == 0u || drawW == 0u)
+    {
+        return hipSuccess;
+    }
+    dim3 const grid((drawW + 31u) / 32u, (rows + 7u) / 8u);
+    hipLaunchKernelGGL(k_lights, grid, dim3(256), 0, s, scene.color, scene.debug_color, gptrs(g), drawW, rows, d_cam, camIndex,
+                       d_lights, lightCount);
+    return hipGetLastError();
+}
+
+hipError_t launch_compose_rowtiles(hipStream_t s, const void* gathered, size_t tileStrideBytes, unsigned nranks,
+                                   unsigned blockRows, const szg_image& dst, unsigned width, unsigned height)
+{
+    if (width == 0u || height == 0u)
+    {
+        return hipSuccess;
+    }
+    unsigned const rowBytes = width * 8u; // RGBA16_UNORM
+    unsigned const rowVecs = rowBytes / 16u;
+    unsigned const gx = (rowVecs + 255u) / 256u;
+    hipLaunchKernelGGL(k_compose, dim3(gx > 8u ? 8u : gx, height), dim3(256), 0, s, static_cast<const uint4*>(gathered),
+                       tileStrideBytes / 16u, nranks, blockRows, static_cast<unsigned char*>(dst.data), dst.pitch_bytes, rowVecs,
+                       height);
+    return hipGetLastError();
+}
+} // namespace szg

@@ -1,0 +1,860 @@
+// szg_api.cpp — the extern "C" boundary declared in include/szg/abi.h.
+//
+// Host-side mirror of renderer/pipelines/skyview.cpp:713-965 and
+// renderer/pipelines/deferred.cpp:145-337, :435-792 with Vulkan, VMA and
+// descriptor plumbing replaced by HIP device pointers and one stream. Every
+// record_* call validates shapes on the host, enqueues, and returns; in-stream
+// order replaces the reference's full barriers (imageoperations.cpp:18-33).
+
+#include <hip/hip_runtime_api.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "szg/abi.h"
+#include "szg_launch.hpp"
+
+namespace
+{
+thread_local char g_error[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof g_error, fmt, ap);
+    va_end(ap);
+    fprintf(stderr, "[szg] error: %s\n", g_error);
+    return code;
+}
+int fail_hip(hipError_t e, const char* what)
+{
+    return fail(e == hipErrorOutOfMemory ? SZG_ERR_OUT_OF_MEMORY : SZG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+}
+#define SZG_HIP(expr)                                                                                                          \
+    do                                                                                                                         \
+    {                                                                                                                          \
+        hipError_t const _e = (expr);                                                                                          \
+        if (_e != hipSuccess)                                                                                                  \
+        {                                                                                                                      \
+            return fail_hip(_e, #expr);                                                                                        \
+        }                                                                                                                      \
+    } while (0)
+
+unsigned texel_bytes(unsigned fmt)
+{
+    switch (fmt)
+    {
+    case SZG_FORMAT_RGBA16_SFLOAT:
+    case SZG_FORMAT_RGBA16_UNORM:
+        return 8;
+    case SZG_FORMAT_RGBA32_SFLOAT:
+        return 16;
+    case SZG_FORMAT_D32_SFLOAT:
+        return 4;
+    default:
+        return 0;
+    }
+}
+
+// An image must be present, of the expected format, at least w x h, with a
+// pitch that covers its rows and keeps texels naturally aligned.
+bool check_image(const szg_image& im, unsigned fmt, unsigned w, unsigned h, const char* name)
+{
+    unsigned const tb = texel_bytes(fmt);
+    if (im.data == nullptr)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "%s: data is NULL", name);
+        return false;
+    }
+    if (im.format != fmt)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "%s: format %u, expected %u", name, im.format, fmt);
+        return false;
+    }
+    if (im.width < w || im.height < h)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "%s: %ux%u smaller than the required %ux%u", name, im.width, im.height, w, h);
+        return false;
+    }
+    if ((size_t)im.pitch_bytes < (size_t)im.width * tb || im.pitch_bytes % tb != 0 ||
+        (reinterpret_cast<uintptr_t>(im.data) % tb) != 0)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "%s: pitch %u / alignment invalid for %u-byte texels", name, im.pitch_bytes, tb);
+        return false;
+    }
+    return true;
+}
+
+bool check_gbuffer(const szg_gbuffer* g, unsigned w, unsigned h)
+{
+    if (g == nullptr)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "gbuffer is NULL");
+        return false;
+    }
+    return check_image(g->diffuse, SZG_FORMAT_RGBA16_SFLOAT, w, h, "gbuffer.diffuse") &&
+           check_image(g->specular, SZG_FORMAT_RGBA16_SFLOAT, w, h, "gbuffer.specular") &&
+           check_image(g->normal, SZG_FORMAT_RGBA16_SFLOAT, w, h, "gbuffer.normal") &&
+           check_image(g->worldPosition, SZG_FORMAT_RGBA32_SFLOAT, w, h, "gbuffer.worldPosition") &&
+           check_image(g->occlusionRoughnessMetallic, SZG_FORMAT_RGBA16_SFLOAT, w, h, "gbuffer.occlusionRoughnessMetallic");
+}
+
+bool check_scene(const szg_scene_texture* s, unsigned w, unsigned h, bool needDepth)
+{
+    if (s == nullptr)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "scene_texture is NULL");
+        return false;
+    }
+    if (!check_image(s->color, SZG_FORMAT_RGBA16_UNORM, w, h, "scene_texture.color"))
+    {
+        return false;
+    }
+    if (needDepth && !check_image(s->depth, SZG_FORMAT_D32_SFLOAT, w, h, "scene_texture.depth"))
+    {
+        return false;
+    }
+    if (s->debug_color.data != nullptr && !check_image(s->debug_color, SZG_FORMAT_RGBA32_SFLOAT, w, h, "scene_texture.debug_color"))
+    {
+        return false;
+    }
+    return true;
+}
+
+// Resolve the tile: returns false (with error) if inconsistent.
+bool resolve_tile(const szg_rowtile* tile, unsigned drawH, szg::TileArgs& out)
+{
+    if (tile == nullptr || tile->nranks <= 1u)
+    {
+        out = szg::TileArgs{1u, 0u, 1u, drawH};
+        return true;
+    }
+    if (tile->block_rows == 0u || tile->rank >= tile->nranks)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "rowtile: block_rows %u rank %u nranks %u", tile->block_rows, tile->rank, tile->nranks);
+        return false;
+    }
+    unsigned const expect = szg_rowtile_local_rows(drawH, tile->block_rows, tile->rank, tile->nranks);
+    if (tile->local_rows != expect)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "rowtile: local_rows %u, expected %u for a %u-row frame", tile->local_rows, expect, drawH);
+        return false;
+    }
+    out = szg::TileArgs{tile->block_rows, tile->rank, tile->nranks, tile->local_rows};
+    return true;
+}
+
+// Small ring of pinned staging buffers for host -> device parameter uploads
+// (the reference's TStagedBuffer staging half, buffers.hpp:209-299). A slot is
+// reused only after the copy that read it has completed.
+struct StagingRing
+{
+    static constexpr int SLOTS = 8;
+    void* host[SLOTS] = {};
+    hipEvent_t done[SLOTS] = {};
+    bool used[SLOTS] = {};
+    size_t bytes = 0;
+    int next = 0;
+
+    int init(size_t n)
+    {
+        bytes = n;
+        for (int i = 0; i < SLOTS; i++)
+        {
+            SZG_HIP(hipHostMalloc(&host[i], n, hipHostMallocDefault));
+            SZG_HIP(hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+        }
+        return SZG_OK;
+    }
+    void destroy()
+    {
+        for (int i = 0; i < SLOTS; i++)
+        {
+            if (done[i] != nullptr)
+            {
+                (void)hipEventDestroy(done[i]);
+            }
+            if (host[i] != nullptr)
+            {
+                (void)hipHostFree(host[i]);
+            }
+            host[i] = nullptr;
+            done[i] = nullptr;
+        }
+    }
+    // Copy `n` bytes from `src` (host) to `dst` (device) on `stream`.
+    int upload(hipStream_t stream, void* dst, const void* src, size_t n)
+    {
+        if (n == 0)
+        {
+            return SZG_OK;
+        }
+        if (n > bytes)
+        {
+            return fail(SZG_ERR_CAPACITY, "staging upload of %zu bytes exceeds %zu", n, bytes);
+        }
+        int const s = next;
+        next = (next + 1) % SLOTS;
+        if (used[s])
+        {
+            SZG_HIP(hipEventSynchronize(done[s]));
+        }
+        std::memcpy(host[s], src, n);
+        SZG_HIP(hipMemcpyAsync(dst, host[s], n, hipMemcpyHostToDevice, stream));
+        SZG_HIP(hipEventRecord(done[s], stream));
+        used[s] = true;
+        return SZG_OK;
+    }
+};
+
+int select_device(int device)
+{
+    int count = 0;
+    hipError_t const e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+    {
+        return fail(SZG_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    }
+    if (device < 0 || device >= count)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "device %d out of range [0, %d)", device, count);
+    }
+    SZG_HIP(hipSetDevice(device));
+    return SZG_OK;
+}
+
+szg_image make_image(void* data, unsigned w, unsigned h, unsigned fmt)
+{
+    szg_image im;
+    im.data = data;
+    im.width = w;
+    im.height = h;
+    im.pitch_bytes = w * texel_bytes(fmt);
+    im.format = fmt;
+    return im;
+}
+} // namespace
+
+// ---------------------------------------------------------------------------
+struct szg_skyview
+{
+    int device = 0;
+    szg_skyview_desc desc{};
+    float* d_transmittance = nullptr;
+    float* d_skyview = nullptr;
+    // LUT cache keys (SZG_SKYVIEW_CACHE_LUTS)
+    bool haveTransmittance = false, haveSkyview = false;
+};
+
+struct szg_deferred
+{
+    int device = 0;
+    szg_deferred_desc desc{};
+    szg_deferred_configuration config{};
+    szg_gbuffer gbuffer{};
+    void* d_gbufferPlanes[5] = {};
+    std::vector<szg_image> shadowImages; // host table returned by szg_deferred_shadow_maps
+    szg_shadowmaps shadowMaps{};
+    void* d_ownedShadowMaps = nullptr;
+    szg_spot_light_packed* d_spots = nullptr;
+    szg::ShadowSlot* d_slots = nullptr;
+    szg::LightRec* d_lightRecs = nullptr;
+    szg_fill_box* d_boxes = nullptr;
+    unsigned maxBoxes = 1024;
+    unsigned maxDirectional = 16;
+    StagingRing staging;
+};
+
+extern "C" {
+
+int szg_abi_version(void) { return SZG_ABI_VERSION; }
+const char* szg_last_error(void) { return g_error; }
+
+int szg_device_count(void)
+{
+    int count = 0;
+    hipError_t const e = hipGetDeviceCount(&count);
+    if (e != hipSuccess)
+    {
+        return fail(SZG_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    return count;
+}
+
+uint32_t szg_rowtile_local_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uint32_t nranks)
+{
+    if (nranks <= 1u)
+    {
+        return height;
+    }
+    if (block_rows == 0u || rank >= nranks)
+    {
+        return 0u;
+    }
+    uint32_t const nblocks = (height + block_rows - 1u) / block_rows;
+    uint32_t rows = 0;
+    for (uint32_t b = rank; b < nblocks; b += nranks)
+    {
+        uint32_t const begin = b * block_rows;
+        uint32_t const end = begin + block_rows < height ? begin + block_rows : height;
+        rows += end - begin;
+    }
+    return rows;
+}
+
+// ---------------------------------------------------------------------------
+// SkyViewComputePipeline
+// ---------------------------------------------------------------------------
+int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int device)
+{
+    if (out == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_create: out is NULL");
+    }
+    *out = nullptr;
+    szg_skyview_desc d{512u, 128u, 2048u, 1024u, 0u, 0u};
+    if (desc != nullptr)
+    {
+        d = *desc;
+    }
+    if (d.transmittance_width < 2u || d.transmittance_height < 2u || d.skyview_width < 2u || d.skyview_height < 2u ||
+        d.transmittance_width > 16384u || d.transmittance_height > 16384u || d.skyview_width > 16384u ||
+        d.skyview_height > 16384u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_create: LUT extents out of range");
+    }
+    int const rc = select_device(device);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    szg_skyview* p = new (std::nothrow) szg_skyview();
+    if (p == nullptr)
+    {
+        return fail(SZG_ERR_OUT_OF_MEMORY, "szg_skyview_create: host allocation failed");
+    }
+    p->device = device;
+    p->desc = d;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_transmittance),
+                             (size_t)d.transmittance_width * d.transmittance_height * 16u);
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_skyview), (size_t)d.skyview_width * d.skyview_height * 16u);
+    }
+    if (e != hipSuccess)
+    {
+        szg_skyview_destroy(p);
+        return fail_hip(e, "szg_skyview_create: hipMalloc");
+    }
+    *out = p;
+    return SZG_OK;
+}
+
+void szg_skyview_destroy(szg_skyview_t* p)
+{
+    if (p == nullptr)
+    {
+        return;
+    }
+    (void)hipSetDevice(p->device);
+    if (p->d_transmittance != nullptr)
+    {
+        (void)hipFree(p->d_transmittance);
+    }
+    if (p->d_skyview != nullptr)
+    {
+        (void)hipFree(p->d_skyview);
+    }
+    delete p;
+}
+
+int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out)
+{
+    if (p == nullptr || out == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_transmittance_lut: NULL argument");
+    }
+    *out = make_image(p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, SZG_FORMAT_RGBA32_SFLOAT);
+    return SZG_OK;
+}
+
+int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out)
+{
+    if (p == nullptr || out == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_skyview_lut: NULL argument");
+    }
+    *out = make_image(p->d_skyview, p->desc.skyview_width, p->desc.skyview_height, SZG_FORMAT_RGBA32_SFLOAT);
+    return SZG_OK;
+}
+
+int szg_skyview_record_transmittance(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                     const szg_atmosphere_packed* d_atmospheres)
+{
+    if (p == nullptr || d_atmospheres == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_transmittance: NULL argument");
+    }
+    SZG_HIP(szg::launch_transmittance(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, p->d_transmittance,
+                                      p->desc.transmittance_width, p->desc.transmittance_height));
+    p->haveTransmittance = true;
+    return SZG_OK;
+}
+
+int szg_skyview_record_skyview_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                   const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                                   const szg_camera_packed* d_cameras)
+{
+    if (p == nullptr || d_atmospheres == nullptr || d_cameras == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_skyview_lut: NULL argument");
+    }
+    SZG_HIP(szg::launch_skyview(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, d_cameras, view_camera_index,
+                                p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
+                                p->desc.skyview_width, p->desc.skyview_height));
+    p->haveSkyview = true;
+    return SZG_OK;
+}
+
+int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture, szg_rect draw_rect,
+                                 const szg_rowtile* tile, const szg_gbuffer* gbuffer, const szg_shadowmaps* shadow_maps,
+                                 uint32_t atmosphere_index, const szg_atmosphere_packed* d_atmospheres,
+                                 uint32_t view_camera_index, const szg_camera_packed* d_cameras, uint32_t sun_light_index,
+                                 const szg_directional_light_packed* d_lights)
+{
+    if (p == nullptr || d_atmospheres == nullptr || d_cameras == nullptr || d_lights == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_composite: NULL argument");
+    }
+    if (draw_rect.width == 0u || draw_rect.height == 0u)
+    {
+        return SZG_OK; // empty extent: nothing to dispatch (computeDispatchCount(0) == 0)
+    }
+    szg::TileArgs t{};
+    if (!resolve_tile(tile, draw_rect.height, t))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    if (!check_scene(scene_texture, draw_rect.width, t.local_rows, true) || !check_gbuffer(gbuffer, draw_rect.width, t.local_rows))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    // camera.comp:369 indexes shadowMaps[sunLightIndex]; only that slot is needed.
+    szg::ShadowSlot sun{nullptr, 0u, 0u, 0u, 0u};
+    unsigned slotCount = 0;
+    if (shadow_maps != nullptr && shadow_maps->maps != nullptr && sun_light_index < shadow_maps->count &&
+        shadow_maps->maps[sun_light_index].data != nullptr)
+    {
+        const szg_image& m = shadow_maps->maps[sun_light_index];
+        if (!check_image(m, SZG_FORMAT_D32_SFLOAT, 1u, 1u, "shadow map"))
+        {
+            return SZG_ERR_INVALID_ARGUMENT;
+        }
+        sun = szg::ShadowSlot{static_cast<const float*>(m.data), m.width, m.height, m.pitch_bytes / 4u, 0u};
+        slotCount = sun_light_index + 1u;
+    }
+    (void)slotCount;
+    SZG_HIP(szg::launch_composite(static_cast<hipStream_t>(stream), *scene_texture, draw_rect.width, draw_rect.height, t, *gbuffer,
+                                  sun, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, d_lights, sun_light_index,
+                                  p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
+                                  p->desc.skyview_width, p->desc.skyview_height));
+    return SZG_OK;
+}
+
+int szg_skyview_record_draw_commands(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture, szg_rect draw_rect,
+                                     const szg_rowtile* tile, const szg_gbuffer* gbuffer, const szg_shadowmaps* shadow_maps,
+                                     uint32_t atmosphere_index, const szg_atmosphere_packed* d_atmospheres,
+                                     uint32_t view_camera_index, const szg_camera_packed* d_cameras, uint32_t sun_light_index,
+                                     const szg_directional_light_packed* d_lights)
+{
+    // skyview.cpp:795-845, :847-893, :895-910: three dispatches in this order, every frame.
+    int rc = szg_skyview_record_transmittance(p, stream, atmosphere_index, d_atmospheres);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    rc = szg_skyview_record_skyview_lut(p, stream, atmosphere_index, d_atmospheres, view_camera_index, d_cameras);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    return szg_skyview_record_composite(p, stream, scene_texture, draw_rect, tile, gbuffer, shadow_maps, atmosphere_index,
+                                        d_atmospheres, view_camera_index, d_cameras, sun_light_index, d_lights);
+}
+
+// ---------------------------------------------------------------------------
+// DeferredShadingPipeline
+// ---------------------------------------------------------------------------
+int szg_deferred_create(szg_deferred_t** out, const szg_deferred_desc* desc, int device)
+{
+    if (out == nullptr || desc == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_create: NULL argument");
+    }
+    *out = nullptr;
+    if (desc->capacity_width == 0u || desc->capacity_height == 0u || desc->capacity_width > 32768u ||
+        desc->capacity_height > 32768u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_create: capacity %ux%u out of range", desc->capacity_width,
+                    desc->capacity_height);
+    }
+    if (desc->max_spot_lights > 65536u || desc->max_shadow_maps > 65536u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_create: light/shadow capacity out of range");
+    }
+    int const rc = select_device(device);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    szg_deferred* p = new (std::nothrow) szg_deferred();
+    if (p == nullptr)
+    {
+        return fail(SZG_ERR_OUT_OF_MEMORY, "szg_deferred_create: host allocation failed");
+    }
+    p->device = device;
+    p->desc = *desc;
+    unsigned const W = desc->capacity_width, H = desc->capacity_height;
+    unsigned const fmts[5] = {SZG_FORMAT_RGBA16_SFLOAT, SZG_FORMAT_RGBA16_SFLOAT, SZG_FORMAT_RGBA16_SFLOAT,
+                              SZG_FORMAT_RGBA32_SFLOAT, SZG_FORMAT_RGBA16_SFLOAT};
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 5 && e == hipSuccess; i++)
+    {
+        size_t const bytes = (size_t)W * H * texel_bytes(fmts[i]);
+        e = hipMalloc(&p->d_gbufferPlanes[i], bytes);
+        if (e == hipSuccess)
+        {
+            // attachments are cleared to 0 at the start of every G-buffer pass (deferred.cpp:493-560)
+            e = hipMemset(p->d_gbufferPlanes[i], 0, bytes);
+        }
+    }
+    unsigned const nSpots = desc->max_spot_lights > 0u ? desc->max_spot_lights : 1u;
+    unsigned const nSlots = desc->max_shadow_maps > 0u ? desc->max_shadow_maps : 1u;
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_spots), (size_t)nSpots * sizeof(szg_spot_light_packed));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_slots), (size_t)nSlots * sizeof(szg::ShadowSlot));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMemset(p->d_slots, 0, (size_t)nSlots * sizeof(szg::ShadowSlot));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_lightRecs), (size_t)(nSpots + p->maxDirectional) * sizeof(szg::LightRec));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_boxes), (size_t)p->maxBoxes * sizeof(szg_fill_box));
+    }
+    p->shadowImages.assign(desc->max_shadow_maps, szg_image{nullptr, 0u, 0u, 0u, SZG_FORMAT_D32_SFLOAT});
+    if (e == hipSuccess && desc->shadow_map_dim > 0u && desc->max_shadow_maps > 0u)
+    {
+        // D32F array, cleared to 0 = far = unoccluded (shadowpass.cpp:188-248). Producing the
+        // depth (triangle raster) is outside this path.
+        size_t const one = (size_t)desc->shadow_map_dim * desc->shadow_map_dim * 4u;
+        e = hipMalloc(&p->d_ownedShadowMaps, one * desc->max_shadow_maps);
+        if (e == hipSuccess)
+        {
+            e = hipMemset(p->d_ownedShadowMaps, 0, one * desc->max_shadow_maps);
+        }
+        if (e == hipSuccess)
+        {
+            for (unsigned i = 0; i < desc->max_shadow_maps; i++)
+            {
+                p->shadowImages[i] = make_image(static_cast<unsigned char*>(p->d_ownedShadowMaps) + one * i, desc->shadow_map_dim,
+                                                desc->shadow_map_dim, SZG_FORMAT_D32_SFLOAT);
+            }
+        }
+    }
+    if (e != hipSuccess)
+    {
+        szg_deferred_destroy(p);
+        return fail_hip(e, "szg_deferred_create: device allocation");
+    }
+    size_t stagingBytes = (size_t)nSpots * sizeof(szg_spot_light_packed);
+    if ((size_t)nSlots * sizeof(szg::ShadowSlot) > stagingBytes)
+    {
+        stagingBytes = (size_t)nSlots * sizeof(szg::ShadowSlot);
+    }
+    if ((size_t)p->maxBoxes * sizeof(szg_fill_box) > stagingBytes)
+    {
+        stagingBytes = (size_t)p->maxBoxes * sizeof(szg_fill_box);
+    }
+    int const src = p->staging.init(stagingBytes);
+    if (src != SZG_OK)
+    {
+        szg_deferred_destroy(p);
+        return src;
+    }
+    p->gbuffer.diffuse = make_image(p->d_gbufferPlanes[0], W, H, SZG_FORMAT_RGBA16_SFLOAT);
+    p->gbuffer.specular = make_image(p->d_gbufferPlanes[1], W, H, SZG_FORMAT_RGBA16_SFLOAT);
+    p->gbuffer.normal = make_image(p->d_gbufferPlanes[2], W, H, SZG_FORMAT_RGBA16_SFLOAT);
+    p->gbuffer.worldPosition = make_image(p->d_gbufferPlanes[3], W, H, SZG_FORMAT_RGBA32_SFLOAT);
+    p->gbuffer.occlusionRoughnessMetallic = make_image(p->d_gbufferPlanes[4], W, H, SZG_FORMAT_RGBA16_SFLOAT);
+    p->shadowMaps.count = desc->max_shadow_maps;
+    p->shadowMaps.padding = 0;
+    p->shadowMaps.maps = p->shadowImages.empty() ? nullptr : p->shadowImages.data();
+    *out = p;
+    return SZG_OK;
+}
+
+void szg_deferred_destroy(szg_deferred_t* p)
+{
+    if (p == nullptr)
+    {
+        return;
+    }
+    (void)hipSetDevice(p->device);
+    (void)hipDeviceSynchronize();
+    for (void* plane : p->d_gbufferPlanes)
+    {
+        if (plane != nullptr)
+        {
+            (void)hipFree(plane);
+        }
+    }
+    void* const rest[] = {p->d_ownedShadowMaps, p->d_spots, p->d_slots, p->d_lightRecs, p->d_boxes};
+    for (void* r : rest)
+    {
+        if (r != nullptr)
+        {
+            (void)hipFree(r);
+        }
+    }
+    p->staging.destroy();
+    delete p;
+}
+
+const szg_gbuffer* szg_deferred_gbuffer(szg_deferred_t* p) { return p != nullptr ? &p->gbuffer : nullptr; }
+const szg_shadowmaps* szg_deferred_shadow_maps(szg_deferred_t* p) { return p != nullptr ? &p->shadowMaps : nullptr; }
+
+int szg_deferred_set_shadow_map(szg_deferred_t* p, uint32_t index, const szg_image* map)
+{
+    if (p == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_set_shadow_map: NULL pipeline");
+    }
+    if (index >= p->shadowImages.size())
+    {
+        return fail(SZG_ERR_CAPACITY, "szg_deferred_set_shadow_map: slot %u >= capacity %zu", index, p->shadowImages.size());
+    }
+    if (map == nullptr || map->data == nullptr)
+    {
+        p->shadowImages[index] = szg_image{nullptr, 0u, 0u, 0u, SZG_FORMAT_D32_SFLOAT};
+        return SZG_OK;
+    }
+    if (!check_image(*map, SZG_FORMAT_D32_SFLOAT, 1u, 1u, "shadow map"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    p->shadowImages[index] = *map;
+    return SZG_OK;
+}
+
+int szg_deferred_get_configuration(const szg_deferred_t* p, szg_deferred_configuration* out)
+{
+    if (p == nullptr || out == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_get_configuration: NULL argument");
+    }
+    *out = p->config;
+    return SZG_OK;
+}
+
+int szg_deferred_set_configuration(szg_deferred_t* p, const szg_deferred_configuration* cfg)
+{
+    if (p == nullptr || cfg == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_set_configuration: NULL argument");
+    }
+    p->config = *cfg;
+    return SZG_OK;
+}
+
+int szg_deferred_record_gbuffer_fill(szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
+                                     const szg_scene_texture* scene_texture, uint32_t view_camera_index,
+                                     const szg_camera_packed* d_cameras, const szg_fill_scene* geometry)
+{
+    if (p == nullptr || d_cameras == nullptr || geometry == nullptr || scene_texture == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_gbuffer_fill: NULL argument");
+    }
+    if (draw_rect.width == 0u || draw_rect.height == 0u)
+    {
+        return SZG_OK;
+    }
+    szg::TileArgs t{};
+    if (!resolve_tile(tile, draw_rect.height, t))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    if (!check_gbuffer(&p->gbuffer, draw_rect.width, t.local_rows) ||
+        !check_image(scene_texture->depth, SZG_FORMAT_D32_SFLOAT, draw_rect.width, t.local_rows, "scene_texture.depth"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    if (geometry->box_count > p->maxBoxes || (geometry->box_count > 0u && geometry->boxes == nullptr))
+    {
+        return fail(SZG_ERR_CAPACITY, "szg_deferred_record_gbuffer_fill: %u boxes (capacity %u)", geometry->box_count, p->maxBoxes);
+    }
+    if (!(geometry->checker_cell > 0.0f))
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_gbuffer_fill: checker_cell must be > 0");
+    }
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    int const rc = p->staging.upload(s, p->d_boxes, geometry->boxes, (size_t)geometry->box_count * sizeof(szg_fill_box));
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    SZG_HIP(szg::launch_gbuffer_fill(s, *scene_texture, draw_rect.width, draw_rect.height, t, p->gbuffer, d_cameras,
+                                     view_camera_index, geometry->ground_y, geometry->ground_half_extent, geometry->checker_cell,
+                                     geometry->ground_roughness, p->d_boxes, geometry->box_count));
+    return SZG_OK;
+}
+
+int szg_deferred_record_lights(szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
+                               const szg_scene_texture* scene_texture, uint32_t atmospheric_directional_lights_count,
+                               const szg_directional_light_packed* d_directional_lights, uint32_t directional_light_count,
+                               const szg_spot_light_packed* h_spot_lights, uint32_t spot_light_count, uint32_t view_camera_index,
+                               const szg_camera_packed* d_cameras)
+{
+    if (p == nullptr || d_cameras == nullptr || scene_texture == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_lights: NULL argument");
+    }
+    if (directional_light_count > 0u && d_directional_lights == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_lights: directional lights NULL");
+    }
+    if (spot_light_count > 0u && h_spot_lights == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_lights: spot lights NULL");
+    }
+    if (spot_light_count > p->desc.max_spot_lights)
+    {
+        return fail(SZG_ERR_CAPACITY, "szg_deferred_record_lights: %u spot lights exceed the capacity %u", spot_light_count,
+                    p->desc.max_spot_lights);
+    }
+    unsigned const skip = atmospheric_directional_lights_count;
+    unsigned const nDir = directional_light_count > skip ? directional_light_count - skip : 0u;
+    if (nDir > p->maxDirectional)
+    {
+        return fail(SZG_ERR_CAPACITY, "szg_deferred_record_lights: %u directional lights exceed the capacity %u", nDir,
+                    p->maxDirectional);
+    }
+    if (draw_rect.width == 0u || draw_rect.height == 0u)
+    {
+        return SZG_OK;
+    }
+    szg::TileArgs t{};
+    if (!resolve_tile(tile, draw_rect.height, t))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    if (!check_scene(scene_texture, draw_rect.width, t.local_rows, false) ||
+        !check_gbuffer(&p->gbuffer, draw_rect.width, t.local_rows))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+
+    // deferred.cpp:458-474: upload the spot lights to the pipeline's own buffer
+    int rc = p->staging.upload(s, p->d_spots, h_spot_lights, (size_t)spot_light_count * sizeof(szg_spot_light_packed));
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    // shadow-map slot table (descriptor array of shadowpass.cpp:300-340)
+    unsigned const slotCount = (unsigned)p->shadowImages.size();
+    if (slotCount > 0u)
+    {
+        std::vector<szg::ShadowSlot> slots(slotCount);
+        for (unsigned i = 0; i < slotCount; i++)
+        {
+            const szg_image& m = p->shadowImages[i];
+            slots[i] = szg::ShadowSlot{static_cast<const float*>(m.data), m.width, m.height, m.pitch_bytes / 4u, 0u};
+        }
+        rc = p->staging.upload(s, p->d_slots, slots.data(), slots.size() * sizeof(szg::ShadowSlot));
+        if (rc != SZG_OK)
+        {
+            return rc;
+        }
+    }
+    SZG_HIP(szg::launch_light_prep(s, d_directional_lights, directional_light_count, skip, p->d_spots, spot_light_count, p->d_slots,
+                                   slotCount, p->d_lightRecs));
+    SZG_HIP(szg::launch_lights(s, *scene_texture, draw_rect.width, draw_rect.height, t, p->gbuffer, d_cameras, view_camera_index,
+                               p->d_lightRecs, nDir + spot_light_count));
+    return SZG_OK;
+}
+
+int szg_deferred_record_draw_commands(szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
+                                      const szg_scene_texture* scene_texture, uint32_t atmospheric_directional_lights_count,
+                                      const szg_directional_light_packed* d_directional_lights,
+                                      uint32_t directional_light_count, const szg_spot_light_packed* h_spot_lights,
+                                      uint32_t spot_light_count, uint32_t view_camera_index, const szg_camera_packed* d_cameras,
+                                      const szg_fill_scene* geometry)
+{
+    if (geometry != nullptr)
+    {
+        int const rc =
+            szg_deferred_record_gbuffer_fill(p, stream, draw_rect, tile, scene_texture, view_camera_index, d_cameras, geometry);
+        if (rc != SZG_OK)
+        {
+            return rc;
+        }
+    }
+    return szg_deferred_record_lights(p, stream, draw_rect, tile, scene_texture, atmospheric_directional_lights_count,
+                                      d_directional_lights, directional_light_count, h_spot_lights, spot_light_count,
+                                      view_camera_index, d_cameras);
+}
+
+int szg_compose_rowtiles(void* stream, const void* gathered, size_t tile_stride_bytes, uint32_t nranks, uint32_t block_rows,
+                         const szg_image* dst, uint32_t width, uint32_t height)
+{
+    if (gathered == nullptr || dst == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_compose_rowtiles: NULL argument");
+    }
+    if (nranks == 0u || block_rows == 0u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_compose_rowtiles: nranks/block_rows must be > 0");
+    }
+    if (!check_image(*dst, SZG_FORMAT_RGBA16_UNORM, width, height, "compose dst"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    if ((width * 8u) % 16u != 0u || tile_stride_bytes % 16u != 0u || dst->pitch_bytes % 16u != 0u ||
+        reinterpret_cast<uintptr_t>(gathered) % 16u != 0u || reinterpret_cast<uintptr_t>(dst->data) % 16u != 0u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_compose_rowtiles: rows must be 16-byte multiples and 16-byte aligned");
+    }
+    size_t maxRows = 0;
+    for (uint32_t r = 0; r < nranks; r++)
+    {
+        size_t const rows = szg_rowtile_local_rows(height, block_rows, r, nranks);
+        if (rows > maxRows)
+        {
+            maxRows = rows;
+        }
+    }
+    if (maxRows * width * 8u > tile_stride_bytes)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_compose_rowtiles: tile stride %zu smaller than the largest tile %zu",
+                    tile_stride_bytes, maxRows * width * 8u);
+    }
+    SZG_HIP(szg::launch_compose_rowtiles(static_cast<hipStream_t>(stream), gathered, tile_stride_bytes, nranks, block_rows, *dst,
+                                         width, height));
+    return SZG_OK;
+}
+
+} // extern "C"

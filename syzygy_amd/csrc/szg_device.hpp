@@ -1,0 +1,549 @@
+// szg_device.hpp — device-side math shared by the CDNA4 kernels.
+//
+// Every function keeps the operation ORDER of the GLSL it implements (cited
+// per function, paths relative to the reference's shaders/ directory) so that
+// with -ffp-contract=off the +,-,*,/,sqrt results are bit-identical to a
+// straight evaluation; only exp/pow/trig come from the device math library.
+// What differs from the shaders is purely structural: loop invariants are
+// hoisted into per-ray / per-light / per-atmosphere constants, images are
+// linear buffers, samplers are explicit address arithmetic.
+#pragma once
+
+#include <hip/hip_fp16.h>
+#include <hip/hip_runtime.h>
+
+#include "szg/abi.h"
+
+#define SZG_DEV __device__ __forceinline__
+
+namespace szg
+{
+struct V2
+{
+    float x, y;
+};
+struct V3
+{
+    float x, y, z;
+};
+struct V4
+{
+    float x, y, z, w;
+};
+
+SZG_DEV V3 mk3(float a, float b, float c) { return V3{a, b, c}; }
+SZG_DEV V3 splat(float a) { return V3{a, a, a}; }
+SZG_DEV V3 operator+(V3 a, V3 b) { return V3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+SZG_DEV V3 operator-(V3 a, V3 b) { return V3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+SZG_DEV V3 operator-(V3 a) { return V3{-a.x, -a.y, -a.z}; }
+SZG_DEV V3 operator*(V3 a, V3 b) { return V3{a.x * b.x, a.y * b.y, a.z * b.z}; }
+SZG_DEV V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
+SZG_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
+SZG_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
+SZG_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
+SZG_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+SZG_DEV float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+SZG_DEV float length(V3 a) { return sqrtf(dot(a, a)); }
+SZG_DEV V3 normalize(V3 v)
+{
+    float const s = 1.0f / sqrtf(dot(v, v));
+    return v * s;
+}
+SZG_DEV V2 normalize(V2 v)
+{
+    float const s = 1.0f / sqrtf(dot(v, v));
+    return V2{v.x * s, v.y * s};
+}
+SZG_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+SZG_DEV V3 clamp01(V3 v) { return V3{clampf(v.x, 0.0f, 1.0f), clampf(v.y, 0.0f, 1.0f), clampf(v.z, 0.0f, 1.0f)}; }
+SZG_DEV V3 mix(V3 a, V3 b, V3 w)
+{
+    return V3{a.x * (1.0f - w.x) + b.x * w.x, a.y * (1.0f - w.y) + b.y * w.y, a.z * (1.0f - w.z) + b.z * w.z};
+}
+SZG_DEV float smoothstep(float e0, float e1, float x)
+{
+    float const t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
+    return t * t * (3.0f - 2.0f * t);
+}
+SZG_DEV float safeSqrt(float v) { return sqrtf(fmaxf(v, 0.0f)); } // atmosphere/common.glinl:23-26
+
+// column-major 4x4 times (x, y, z, w), rows summed left to right
+struct M4
+{
+    float m[16];
+};
+SZG_DEV V4 mul(const M4& a, float x, float y, float z, float w)
+{
+    V4 r;
+    r.x = a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w;
+    r.y = a.m[1] * x + a.m[5] * y + a.m[9] * z + a.m[13] * w;
+    r.z = a.m[2] * x + a.m[6] * y + a.m[10] * z + a.m[14] * w;
+    r.w = a.m[3] * x + a.m[7] * y + a.m[11] * z + a.m[15] * w;
+    return r;
+}
+SZG_DEV M4 mul(const M4& a, const M4& b)
+{
+    M4 r;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+        V4 const c = mul(a, b.m[j * 4 + 0], b.m[j * 4 + 1], b.m[j * 4 + 2], b.m[j * 4 + 3]);
+        r.m[j * 4 + 0] = c.x;
+        r.m[j * 4 + 1] = c.y;
+        r.m[j * 4 + 2] = c.z;
+        r.m[j * 4 + 3] = c.w;
+    }
+    return r;
+}
+SZG_DEV M4 load_m4(const szg_mat4& s)
+{
+    M4 r;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        r.m[i] = s.m[i];
+    }
+    return r;
+}
+
+// ---------------------------------------------------------------------------
+// Formats
+// ---------------------------------------------------------------------------
+// imageStore on rgba16 (UNORM16): clamp, scale, round to nearest even.
+SZG_DEV unsigned unorm16(float x)
+{
+    float const c = fminf(fmaxf(x, 0.0f), 1.0f); // NaN -> 0
+    return (unsigned)__float2int_rn(c * 65535.0f);
+}
+SZG_DEV uint2 pack_unorm16x4(float r, float g, float b, float a)
+{
+    return make_uint2(unorm16(r) | (unorm16(g) << 16), unorm16(b) | (unorm16(a) << 16));
+}
+SZG_DEV V4 unpack_half4(uint2 v)
+{
+    __half2 const lo = *reinterpret_cast<const __half2*>(&v.x);
+    __half2 const hi = *reinterpret_cast<const __half2*>(&v.y);
+    float2 const a = __half22float2(lo);
+    float2 const b = __half22float2(hi);
+    return V4{a.x, a.y, b.x, b.y};
+}
+SZG_DEV uint2 pack_half4(float r, float g, float b, float a)
+{
+    __half2 const lo = __floats2half2_rn(r, g);
+    __half2 const hi = __floats2half2_rn(b, a);
+    uint2 o;
+    o.x = *reinterpret_cast<const unsigned*>(&lo);
+    o.y = *reinterpret_cast<const unsigned*>(&hi);
+    return o;
+}
+
+// Linear image view passed by value to kernels.
+struct Img
+{
+    const unsigned char* data;
+    unsigned width, height, pitch;
+};
+struct ImgRW
+{
+    unsigned char* data;
+    unsigned width, height, pitch;
+};
+
+// szg_rowtile: local row -> global row
+struct RowMap
+{
+    unsigned block_rows, rank, nranks;
+};
+SZG_DEV unsigned global_row(const RowMap& m, unsigned local)
+{
+    if (m.nranks <= 1u)
+    {
+        return local;
+    }
+    return ((local / m.block_rows) * m.nranks + m.rank) * m.block_rows + local % m.block_rows;
+}
+
+// ---------------------------------------------------------------------------
+// Atmosphere block in registers/SGPRs + per-atmosphere constants
+// (types/atmosphere.glinl:3-32)
+// ---------------------------------------------------------------------------
+struct Atm
+{
+    V3 scatteringRayleigh;
+    float densityScaleRayleigh;
+    V3 absorptionRayleigh;
+    float planetRadius;
+    V3 scatteringMie;
+    float densityScaleMie;
+    float atmosphereRadius;
+    V3 incidentDirectionSun;
+    V3 scatteringOzone;
+    V3 absorptionOzone;
+    V3 sunIntensitySpectrum;
+    float sunAngularRadius;
+    // hoisted sub-expressions of common.glinl:42-46
+    float Ra2, Rp2, H;
+};
+SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
+{
+    Atm a;
+    a.scatteringRayleigh = mk3(p->scatteringRayleighPerMm[0], p->scatteringRayleighPerMm[1], p->scatteringRayleighPerMm[2]);
+    a.densityScaleRayleigh = p->densityScaleRayleighMm;
+    a.absorptionRayleigh = mk3(p->absorptionRayleighPerMm[0], p->absorptionRayleighPerMm[1], p->absorptionRayleighPerMm[2]);
+    a.planetRadius = p->planetRadiusMm;
+    a.scatteringMie = mk3(p->scatteringMiePerMm[0], p->scatteringMiePerMm[1], p->scatteringMiePerMm[2]);
+    a.densityScaleMie = p->densityScaleMieMm;
+    a.atmosphereRadius = p->atmosphereRadiusMm;
+    a.incidentDirectionSun = mk3(p->incidentDirectionSun[0], p->incidentDirectionSun[1], p->incidentDirectionSun[2]);
+    a.scatteringOzone = mk3(p->scatteringOzonePerMm[0], p->scatteringOzonePerMm[1], p->scatteringOzonePerMm[2]);
+    a.absorptionOzone = mk3(p->absorptionOzonePerMm[0], p->absorptionOzonePerMm[1], p->absorptionOzonePerMm[2]);
+    a.sunIntensitySpectrum = mk3(p->sunIntensitySpectrum[0], p->sunIntensitySpectrum[1], p->sunIntensitySpectrum[2]);
+    a.sunAngularRadius = p->sunAngularRadius;
+    a.Ra2 = a.atmosphereRadius * a.atmosphereRadius;
+    a.Rp2 = a.planetRadius * a.planetRadius;
+    a.H = safeSqrt(a.Ra2 - a.Rp2);
+    return a;
+}
+
+// common.glinl:194-216. Mie absorption uses the Rayleigh coefficient (line 202).
+struct Extinction
+{
+    V3 scatteringRayleigh;
+    V3 scatteringMie;
+    V3 extinction;
+};
+SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude)
+{
+    float const densityRayleigh = expf(-altitude / a.densityScaleRayleigh);
+    V3 const scatteringRayleigh = a.scatteringRayleigh * densityRayleigh;
+    V3 const absorptionRayleigh = a.absorptionRayleigh * densityRayleigh;
+    float const densityMie = expf(-altitude / a.densityScaleMie);
+    V3 const scatteringMie = a.scatteringMie * densityMie;
+    V3 const absorptionMie = a.absorptionRayleigh * densityMie;
+    float const densityOzone = fmaxf(0.0f, 1.0f - fabsf(altitude * 1000.0f - 25.0f) / 15.0f);
+    V3 const scatteringOzone = a.scatteringOzone * densityOzone;
+    V3 const absorptionOzone = a.absorptionOzone * densityOzone;
+    Extinction e;
+    e.scatteringRayleigh = scatteringRayleigh;
+    e.scatteringMie = scatteringMie;
+    e.extinction = scatteringRayleigh + absorptionRayleigh + scatteringMie + absorptionMie + scatteringOzone + absorptionOzone;
+    return e;
+}
+
+// common.glinl:220-260
+SZG_DEV bool raySphere(V3 f, V3 d, float radius, float& t0, float& t1)
+{
+    float const b = -1.0f * dot(f, d);
+    V3 const chord = f + b * d;
+    float const discriminant = radius * radius - dot(chord, chord);
+    float const c = dot(f, f) - radius * radius;
+    if (discriminant < 0.0f)
+    {
+        return false;
+    }
+    float q = b;
+    float const s = sqrtf(discriminant);
+    q = (b < 0.0f) ? (q - s) : (q + s);
+    float a0 = c / q;
+    float a1 = q;
+    if (a0 > a1)
+    {
+        float const tmp = a0;
+        a0 = a1;
+        a1 = tmp;
+    }
+    t0 = a0;
+    t1 = a1;
+    return true;
+}
+
+// common.glinl:284-307
+SZG_DEV float raycastAtmosphere(const Atm& a, V3 origin, V3 direction)
+{
+    float at0 = 0.0f, at1 = 0.0f;
+    bool const hitAtmosphere = raySphere(origin, direction, a.atmosphereRadius, at0, at1) && at1 > 0.0f;
+    at0 = fmaxf(0.0f, at0);
+    float pt0 = 0.0f, pt1 = 0.0f;
+    bool const hitPlanet = raySphere(origin, direction, a.planetRadius, pt0, pt1) && pt0 > 0.0f;
+    if (hitPlanet)
+    {
+        at1 = fminf(pt0, at1);
+    }
+    return hitAtmosphere ? (at1 - at0) : 0.0f;
+}
+
+// ---------------------------------------------------------------------------
+// Transmittance LUT sampler: LINEAR / CLAMP_TO_EDGE / fp32 weights
+// (renderer/pipelines/skyview.cpp:199-207, :339-346)
+// ---------------------------------------------------------------------------
+struct TLut
+{
+    const float4* texels; // RGBA32F, row-major, pitch = width texels
+    int width, height;
+    float fwidth, fheight;
+    // textureCoordFromUnitRange constants (common.glinl:29-32)
+    float u_bias, u_scale, v_bias, v_scale;
+};
+SZG_DEV TLut make_tlut(const float4* texels, int w, int h)
+{
+    TLut t;
+    t.texels = texels;
+    t.width = w;
+    t.height = h;
+    t.fwidth = (float)w;
+    t.fheight = (float)h;
+    t.u_bias = 0.5f / (float)w;
+    t.u_scale = 1.0f - 1.0f / (float)w;
+    t.v_bias = 0.5f / (float)h;
+    t.v_scale = 1.0f - 1.0f / (float)h;
+    return t;
+}
+
+SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float fW, float fH, float s, float t)
+{
+    float const u = s * fW - 0.5f;
+    float const v = t * fH - 0.5f;
+    float const fu = floorf(u);
+    float const fv = floorf(v);
+    float const a = u - fu;
+    float const b = v - fv;
+    int i0 = (int)fu, j0 = (int)fv;
+    int i1 = i0 + 1, j1 = j0 + 1;
+    i0 = min(max(i0, 0), W - 1);
+    i1 = min(max(i1, 0), W - 1);
+    j0 = min(max(j0, 0), H - 1);
+    j1 = min(max(j1, 0), H - 1);
+    float4 const t00 = texels[j0 * W + i0];
+    float4 const t10 = texels[j0 * W + i1];
+    float4 const t01 = texels[j1 * W + i0];
+    float4 const t11 = texels[j1 * W + i1];
+    float const w00 = (1.0f - a) * (1.0f - b);
+    float const w10 = a * (1.0f - b);
+    float const w01 = (1.0f - a) * b;
+    float const w11 = a * b;
+    V3 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    return r;
+}
+
+// common.glinl:40-66 + :138-143 : sample at (radius, mu)
+SZG_DEV V3 sampleT_RadiusMu(const TLut& L, const Atm& a, float radius, float mu)
+{
+    float const rho = safeSqrt(radius * radius - a.Rp2);
+    float const d = fmaxf(-radius * mu + safeSqrt(radius * radius * (mu * mu - 1.0f) + a.Ra2), 0.0f);
+    float const d_min = a.atmosphereRadius - radius;
+    float const d_max = rho + a.H;
+    float const x_mu = (d - d_min) / (d_max - d_min);
+    float const x_radius = rho / a.H;
+    float const s = L.u_bias + x_mu * L.u_scale;
+    float const t = L.v_bias + x_radius * L.v_scale;
+    return bilinear_rgb(L.texels, L.width, L.height, L.fwidth, L.fheight, s, t);
+}
+
+// common.glinl:104-112
+SZG_DEV V3 sampleT_Ray(const TLut& L, const Atm& a, V3 position, V3 direction)
+{
+    float const radius = length(position);
+    float const mu = dot(position, direction) / (length(position) * length(direction));
+    return sampleT_RadiusMu(L, a, radius, mu);
+}
+
+// common.glinl:114-136
+SZG_DEV V3 sampleT_Segment(const TLut& L, const Atm& a, V3 from, V3 to)
+{
+    V3 const direction = normalize(to - from);
+    V3 num, den;
+    if (dot(from, direction) < 0.0f)
+    {
+        V3 const nd = -direction;
+        num = sampleT_Ray(L, a, to, nd);
+        den = sampleT_Ray(L, a, from, nd);
+    }
+    else
+    {
+        num = sampleT_Ray(L, a, from, direction);
+        den = sampleT_Ray(L, a, to, direction);
+    }
+    return clamp01(num / den);
+}
+
+// common.glinl:263-279
+SZG_DEV float phaseRayleigh(float cosine)
+{
+    float const scalar = 3.0f / (16.0f * 3.141592653589793f);
+    return scalar * (1.0f + cosine * cosine);
+}
+SZG_DEV float phaseMie(float cosine, float g)
+{
+    float const scalar = 3.0f / (8.0f * 3.141592653589793f);
+    float const numerator = (1.0f - g * g) * (1.0f + cosine * cosine);
+    float const denominator = (2.0f + g * g) * powf(1.0f + g * g - 2.0f * g * cosine, 1.5f);
+    return scalar * numerator / denominator;
+}
+
+// common.glinl:364-424 computeLuminanceScatteringIntegral, 32 steps.
+// Hoisted (values identical in every iteration of the GLSL loop):
+//   phase functions (line 408-410), sun-disc sin/cos (147-148), the origin-side
+//   LUT tap and mu_sunAndStepDirection of sampleTransmittanceLUT_RayMarchStep /
+//   stepRadiusMu (325, 349/357). stepRadiusMu(originStep, t) is evaluated once
+//   per step and used for both sampleStep (389) and `end` (343).
+SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 direction, float sampleDistance)
+{
+    V3 const scatteringDir = -normalize(direction);
+    float const radius = length(origin);
+    float const mu = dot(origin, direction) / (length(origin) * length(direction));
+    V3 const toSun = -a.incidentDirectionSun;
+    float const mu_sun = dot(origin, toSun) / (length(origin) * length(a.incidentDirectionSun));
+
+    float const incidentCosine = dot(a.incidentDirectionSun, scatteringDir);
+    float const pR = phaseRayleigh(incidentCosine);
+    float const pM = phaseMie(incidentCosine, 0.8f);
+    float const sin_sunRadius = sinf(a.sunAngularRadius);
+    float const cos_sunRadius = cosf(a.sunAngularRadius);
+
+    // stepRadiusMu invariants (common.glinl:325)
+    float const mu_sunAndStep = safeSqrt(mu_sun * mu - safeSqrt((1.0f - mu_sun * mu_sun) * (1.0f - mu * mu)));
+    float const r_mu = radius * mu;
+    float const two_r_mu = 2.0f * radius * mu;
+    float const r2 = radius * radius;
+    float const r_musun = radius * mu_sun;
+    bool const up = mu > 0.0f;
+    V3 const T_origin = sampleT_RadiusMu(L, a, radius, up ? mu : -mu);
+
+    V3 luminance = splat(0.0f);
+    float const dS = sampleDistance / 32.0f;
+#pragma unroll 1
+    for (unsigned i = 0; i < 32u; i++)
+    {
+        float const fi = (float)i;
+        float const t = fi * dS;
+        V3 const begin = origin - (fi * dS) * scatteringDir;
+        V3 const end = origin - ((float)(i + 1u) * dS) * scatteringDir;
+
+        // stepRadiusMu(originStep, t), common.glinl:329-331
+        float const s_radius = safeSqrt(t * t + two_r_mu * t + r2);
+        float const s_mu = (r_mu + t) / s_radius;
+        float const s_musun = (r_musun + t * mu_sunAndStep) / s_radius;
+
+        float const altitude = length(begin) - a.planetRadius;
+
+        // sampleTransmittanceLUT_Sun, common.glinl:145-172
+        float const sin_hz = a.planetRadius / s_radius;
+        float const cos_hz = -safeSqrt(1.0f - sin_hz * sin_hz);
+        V3 const T_atm = sampleT_RadiusMu(L, a, s_radius, s_musun);
+        float const angularFactor = smoothstep(-sin_hz * sin_sunRadius, sin_hz * sin_sunRadius, s_musun - cos_hz * cos_sunRadius);
+        V3 const T_sun = T_atm * angularFactor;
+
+        Extinction const ex = sampleExtinction(a, altitude);
+
+        // sampleTransmittanceLUT_RayMarchStep, common.glinl:336-361
+        V3 T_begin;
+        if (t < 0.0000001f)
+        {
+            T_begin = splat(1.0f);
+        }
+        else
+        {
+            V3 const T_end = sampleT_RadiusMu(L, a, s_radius, up ? s_mu : -s_mu);
+            T_begin = clamp01(up ? (T_origin / T_end) : (T_end / T_origin));
+        }
+
+        V3 const phaseTimesScattering = ex.scatteringRayleigh * pR + ex.scatteringMie * pM;
+        V3 const T_path = sampleT_Segment(L, a, begin, end);
+        V3 const integral = (splat(1.0f) - T_path) / ex.extinction;
+        luminance = luminance + phaseTimesScattering * T_sun * integral * T_begin;
+    }
+    return luminance;
+}
+
+// ---------------------------------------------------------------------------
+// PBR (gbuffer/pbrFunctions.glinl) and shadow maps (shadowmap.glinl)
+// ---------------------------------------------------------------------------
+struct Material
+{
+    V3 position;
+    V3 normal;
+    V3 subscattering;
+    V3 reflectance;
+    float occlusion;
+    float specularPower;
+    float metallic;
+};
+
+// pbrFunctions.glinl:3-20
+SZG_DEV Material convertPBR(V4 position, V4 normal, V4 diffuse, V4 specular, V4 orm)
+{
+    Material m;
+    V3 const spec = mk3(specular.x, specular.y, specular.z);
+    float const mx = fmaxf(fmaxf(spec.x, spec.y), spec.z);
+    V3 const metallicReflectance = (splat(0.5f) * spec) / mx;
+    m.position = mk3(position.x, position.y, position.z);
+    m.normal = mk3(normal.x, normal.y, normal.z);
+    m.subscattering = mk3(diffuse.x, diffuse.y, diffuse.z);
+    m.metallic = orm.z;
+    m.reflectance = mix(splat(0.04f), metallicReflectance, splat(m.metallic));
+    m.occlusion = orm.x;
+    m.specularPower = powf(160.0f, 1.0f - orm.y);
+    return m;
+}
+
+// computeLightContribution's BRDF part (lights.comp:93-108 / camera.comp:258-271):
+// mix(diffuseBRDF, specularBRDF, fresnel) for outgoing light/view directions.
+SZG_DEV V3 brdfMix(const Material& m, V3 lightDir, V3 viewDir)
+{
+    V3 const diffuse = m.subscattering / 3.14159265359f;
+    V3 const h = normalize(lightDir + viewDir);
+    float const microfacet = powf(clampf(dot(h, m.normal), 0.0f, 1.0f), m.specularPower);
+    float const normalization = (m.specularPower + 2.0f) / 8.0f;
+    V3 const specular = splat(normalization * microfacet);
+    float const p = powf(1.0f - clampf(dot(h, lightDir), 0.0f, 1.0f), 5.0f);
+    V3 const fresnel = m.reflectance + (splat(1.0f) - m.reflectance) * p;
+    return mix(diffuse, specular, fresnel);
+}
+
+// pbrFunctions.glinl:22-32
+SZG_DEV V3 computeFresnel(const Material& m, V3 lightOutgoing, V3 viewOutgoing)
+{
+    V3 const h = normalize(lightOutgoing + viewOutgoing);
+    float const p = powf(1.0f - clampf(dot(h, lightOutgoing), 0.0f, 1.0f), 5.0f);
+    return m.reflectance + (splat(1.0f) - m.reflectance) * p;
+}
+
+// shadowmap.glinl:32-64 with NEAREST / CLAMP_TO_BORDER(0) (shadowpass.cpp:29-35).
+// `coord` is shadowCoord / w, (ndx, ndy) the two sqrt terms of computeShadowFrame.
+SZG_DEV float sampleShadowMap(const float* __restrict__ map, unsigned W, unsigned H, unsigned pitchFloats, V3 coord, float fdx,
+                              float fdy)
+{
+    float const fragmentDepth = coord.z;
+    float const fW = (float)(int)W;
+    float const fH = (float)(int)H;
+    float const dx = 1.5f * fdx / fW;
+    float const dy = 1.5f * fdy / fH;
+    float summed = 0.0f;
+#pragma unroll
+    for (int y = -2; y <= 2; y++)
+    {
+#pragma unroll
+        for (int x = -2; x <= 2; x++)
+        {
+            float const s = coord.x + (float)x * dx;
+            float const t = coord.y + (float)y * dy;
+            float const fx = floorf(s * fW);
+            float const fy = floorf(t * fH);
+            float occluder = 0.0f;
+            if (fx >= 0.0f && fy >= 0.0f && fx < fW && fy < fH)
+            {
+                occluder = map[(unsigned)fy * pitchFloats + (unsigned)fx];
+            }
+            if (occluder > 0.0f && occluder > fragmentDepth)
+            {
+                summed += 1.0f;
+            }
+        }
+    }
+    return 1.0f - summed / 25.0f;
+}
+
+} // namespace szg

@@ -1,0 +1,62 @@
+// szg_launch.hpp — internal launch interface between the C-ABI layer (szg_api.cpp)
+// and the kernel translation units. Not part of the public boundary.
+#pragma once
+
+#include <hip/hip_runtime_api.h>
+
+#include "szg/abi.h"
+
+namespace szg
+{
+// Per-light record produced by the prep kernel, consumed by the lights kernel
+// through scalar (wave-uniform) loads. 36 dwords.
+struct LightRec
+{
+    float shadowMatrix[16]; // TO_TEX_COORD_MAT * projection * view (shadowmap.glinl:19)
+    float dir[3];           // normalize(-forward) (lights.comp:67/78)
+    float falloffFactor;
+    float colorStrength[3]; // color.rgb * strength (lights.comp:68/88)
+    float falloffDistance;
+    float position[3];
+    unsigned isSpot;
+    const float* map; // D32F shadow map or nullptr
+    unsigned mapWidth, mapHeight;
+    unsigned mapPitchFloats;
+    unsigned pad[3];
+};
+static_assert(sizeof(LightRec) == 144, "LightRec layout");
+
+// Device-visible shadow-map slot table entry (uploaded by the host).
+struct ShadowSlot
+{
+    const float* map;
+    unsigned width, height, pitchFloats, pad;
+};
+static_assert(sizeof(ShadowSlot) == 24, "ShadowSlot layout");
+
+struct TileArgs
+{
+    unsigned block_rows, rank, nranks, local_rows;
+};
+
+hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, float* lut, unsigned W,
+                                unsigned H);
+hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
+                          unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H);
+hipError_t launch_light_prep(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount, unsigned dirSkip,
+                             const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_slots,
+                             unsigned slotCount, LightRec* d_out);
+hipError_t launch_lights(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
+                         const szg_gbuffer& g, const szg_camera_packed* d_cam, unsigned camIndex, const LightRec* d_lights,
+                         unsigned lightCount);
+hipError_t launch_gbuffer_fill(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
+                               const szg_gbuffer& g, const szg_camera_packed* d_cam, unsigned camIndex, float ground_y,
+                               float ground_half_extent, float checker_cell, float ground_roughness,
+                               const szg_fill_box* d_boxes, unsigned boxCount);
+hipError_t launch_composite(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
+                            const szg_gbuffer& g, ShadowSlot sunSlot, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
+                            unsigned camIndex, const szg_directional_light_packed* d_dir, unsigned sunIndex, const float* tlut,
+                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH);
+hipError_t launch_compose_rowtiles(hipStream_t s, const void* gathered, size_t tileStrideBytes, unsigned nranks,
+                                   unsigned blockRows, const szg_image& dst, unsigned width, unsigned height);
+} // namespace szg

@@ -1,0 +1,449 @@
+"""GPU parity tests: every HIP pass, called through the C-ABI, against the CPU oracle on
+the same seeded inputs. Tolerance: 1e-4 relative on fp32 values
+(north_star), +-1 LSB on the UNORM16 scene colour, bit-exact where the
+arithmetic has no transcendental (G-buffer fill, row tiling, compose).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests import util
+from tests.util import RTOL, assert_close
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("-m gpu tests need a GPU; the product path has no CPU fallback")
+    from oracle import binding as ob
+    from syzygy_amd import abi, pipelines, scene
+
+    class Ctx:
+        pass
+
+    c = Ctx()
+    c.ob, c.abi, c.pl, c.scene = ob, abi, pipelines, scene
+    return c
+
+
+def staged(gpu, inp):
+    pl, abi = gpu.pl, gpu.abi
+    cameras = pl.TStagedBuffer(abi.CameraPacked, 1)
+    atmospheres = pl.TStagedBuffer(abi.AtmospherePacked, 1)
+    lights = pl.TStagedBuffer(abi.DirectionalLightPacked, 2)
+    cameras.push(inp.cam)
+    atmospheres.push(inp.atm)
+    lights.push([inp.sun, inp.moon])
+    for b in (cameras, atmospheres, lights):
+        b.recordCopyToDevice()
+    return cameras, atmospheres, lights
+
+
+# ---------------------------------------------------------------------------
+# transmittance LUT (BASELINE config 1: 256x64; reference-native 512x128)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("extent", [(256, 64), (512, 128), (64, 16), (33, 7)])
+def test_transmittance_lut_matches_oracle(gpu, extent):
+    inp = util.Inputs(64, 64)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=extent, skyview_extent=(64, 32))
+    assert sky is not None
+    sky.recordTransmittance(None, 0, atmospheres)
+    torch.cuda.synchronize()
+    got = sky.download_lut(sky.transmittanceLUT())
+    want = gpu.ob.transmittance_lut(inp.atm, extent[0], extent[1], threads=8)
+    worst = assert_close(got, want, atol=1e-12, what=f"transmittance {extent}")
+    exact = float((got == want).mean())
+    print(f"transmittance {extent}: worst/tol {worst:.3f}, bit-identical fraction {exact:.3f}")
+    sky.destroy()
+
+
+# ---------------------------------------------------------------------------
+# sky-view LUT on an identical transmittance LUT
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("elevation", [70.0, 5.0, -3.0])
+def test_skyview_lut_matches_oracle(gpu, elevation):
+    inp = util.Inputs(64, 64, elevation_degrees=elevation)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(512, 128), skyview_extent=(512, 256))
+    tlut = gpu.ob.transmittance_lut(inp.atm, 512, 128, threads=8)
+    sky.upload_lut(sky.transmittanceLUT(), tlut)
+    sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    torch.cuda.synchronize()
+    got = sky.download_lut(sky.skyviewLUT())
+    want = gpu.ob.skyview_lut(inp.atm, inp.cam, tlut, 512, 256, threads=8)
+    worst = assert_close(got[..., :3], want[..., :3], atol=1e-9, what=f"skyview elev {elevation}")
+    assert (got[..., 3] == 1.0).all()
+    print(f"skyview elev {elevation}: worst/tol {worst:.3f}")
+    sky.destroy()
+
+
+def test_skyview_lut_reference_size_band(gpu):
+    """Reference-native 2048x1024 LUT: a band of rows around the horizon against the oracle."""
+    inp = util.Inputs(64, 64, elevation_degrees=5.0)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create()
+    tlut = gpu.ob.transmittance_lut(inp.atm, 512, 128, threads=8)
+    sky.upload_lut(sky.transmittanceLUT(), tlut)
+    sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    torch.cuda.synchronize()
+    got = sky.download_lut(sky.skyviewLUT())
+    want = np.zeros((1024, 2048, 4), np.float32)
+    gpu.ob.skyview_lut(inp.atm, inp.cam, tlut, 2048, 1024, row_begin=480, row_end=544, threads=8, out=want)
+    assert_close(got[480:544, :, :3], want[480:544, :, :3], atol=1e-9, what="skyview 2048x1024 rows 480..544")
+    # mirror symmetry in azimuth is NOT exact (u = .5 + .5 cos), but every texel must be finite and >= 0
+    assert np.isfinite(got).all() and (got[..., :3] >= 0).all()
+    sky.destroy()
+
+
+# ---------------------------------------------------------------------------
+# G-buffer fill: arithmetic only -> bit-exact
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("size", [(160, 96), (70, 37), (1, 1)])
+def test_gbuffer_fill_bit_exact(gpu, size):
+    W, H = size
+    inp = util.Inputs(W, H)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    target = gpu.pl.SceneTexture(W, H)
+    deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=1, max_shadow_maps=0)
+    deferred.recordGBufferFill(None, inp.rect, target, 0, cameras, inp.synthetic.fill)
+    torch.cuda.synchronize()
+    got = deferred.download_gbuffer(W, H)
+    frame = gpu.ob.HostFrame(W, H)
+    gpu.ob.gbuffer_fill(frame, inp.rect, None, inp.cam, inp.synthetic.fill, threads=4)
+    for name, want in frame.planes().items():
+        assert (got[name].view(np.uint8) == want.view(np.uint8)).all(), name
+    assert (target.depth.cpu().numpy().view(np.uint32) == frame.depth.view(np.uint32)).all()
+    deferred.cleanup()
+
+
+# ---------------------------------------------------------------------------
+# lights pass
+# ---------------------------------------------------------------------------
+def run_lights_case(gpu, W, H, spots, skip, elevation=70.0, shadow=None, tile=None):
+    inp = util.Inputs(W, H, elevation_degrees=elevation, spots=spots)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    rows = H if tile is None else tile.local_rows
+    frame = gpu.ob.HostFrame(W, rows)
+    gpu.ob.gbuffer_fill(frame, inp.rect, tile, inp.cam, inp.synthetic.fill, threads=8)
+    shadow_host = None
+    keep = []
+    deferred = gpu.pl.DeferredShadingPipeline((W, rows), max_spot_lights=max(spots, 1), max_shadow_maps=spots + 2)
+    if shadow is not None:
+        images = (gpu.abi.Image * (spots + 2))()
+        for slot, depth_map in shadow.items():
+            images[slot] = gpu.ob.host_image(depth_map, gpu.abi.SZG_FORMAT_D32_SFLOAT)
+            t = torch.from_numpy(depth_map).cuda()
+            keep.append(t)
+            deferred.setShadowMap(slot, t)
+        shadow_host = gpu.abi.ShadowMaps(spots + 2, 0, C.cast(images, C.POINTER(gpu.abi.Image)))
+        keep.append(images)
+    gpu.ob.lights(frame, inp.rect, tile, shadow_host, inp.cam, inp.dirs, 2, skip, inp.spots, spots, threads=8)
+
+    target = gpu.pl.SceneTexture(W, rows, debug=True)
+    deferred.upload_gbuffer(frame.planes())
+    deferred.recordLights(None, inp.rect, target, skip, lights, inp.spots if spots else None, 0, cameras, tile=tile)
+    torch.cuda.synchronize()
+    got = target.debug.cpu().numpy()
+    got_q = target.color_numpy()
+    deferred.cleanup()
+    return got, got_q, frame
+
+
+@pytest.mark.parametrize("spots,skip", [(0, 1), (0, 0), (1, 1), (16, 1), (64, 1), (256, 0)])
+def test_lights_match_oracle(gpu, spots, skip):
+    got, got_q, frame = run_lights_case(gpu, 192, 108, spots, skip)
+    worst = assert_close(got, frame.debug, what=f"lights spots={spots} skip={skip}")
+    assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+    assert (got_q[..., 3] == 65535).all()
+    print(f"lights spots={spots} skip={skip}: worst/tol {worst:.3f}")
+
+
+def test_lights_ragged_extent(gpu):
+    got, got_q, frame = run_lights_case(gpu, 70, 37, 8, 1)
+    assert_close(got, frame.debug, what="lights 70x37")
+
+
+def test_lights_background_keeps_clear_colour(gpu):
+    got, got_q, frame = run_lights_case(gpu, 96, 54, 4, 0)
+    background = frame.diffuse[..., 3].astype(np.float32) < 1.0
+    assert background.any() and (~background).any()
+    assert (got_q[background] == np.array([0, 0, 0, 65535], np.uint16)).all()
+
+
+def test_lights_with_shadow_maps(gpu):
+    """25-tap PCF on nearest / clamp-to-border maps (shadowmap.glinl:32-64): random occluder
+    depths for the moon (slot 1) and two spot lights."""
+    rng = np.random.default_rng(0x5A2C)
+    maps = {1: rng.random((64, 64), dtype=np.float32), 2: rng.random((128, 96), dtype=np.float32),
+            5: (rng.random((33, 47), dtype=np.float32) > 0.5).astype(np.float32) * 0.9999}
+    got, got_q, frame = run_lights_case(gpu, 160, 90, 8, 1, shadow=maps)
+    assert_close(got, frame.debug, what="lights with shadow maps")
+    assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+
+
+def test_lights_capacity_is_an_error(gpu):
+    inp = util.Inputs(32, 32, spots=4)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    target = gpu.pl.SceneTexture(32, 32)
+    deferred = gpu.pl.DeferredShadingPipeline((32, 32), max_spot_lights=2, max_shadow_maps=0)
+    from syzygy_amd import SzgError
+
+    with pytest.raises(SzgError) as e:
+        deferred.recordLights(None, inp.rect, target, 1, lights, inp.spots, 0, cameras)
+    assert e.value.code == -5
+    deferred.cleanup()
+
+
+def test_lights_linearity(gpu):
+    """all lights at once == sum of single-light runs, before the UNORM clamp."""
+    W, H, N = 128, 72, 6
+    inp = util.Inputs(W, H, spots=N)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    target = gpu.pl.SceneTexture(W, H, debug=True)
+    deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=N, max_shadow_maps=0)
+    deferred.recordGBufferFill(None, inp.rect, target, 0, cameras, inp.synthetic.fill)
+    deferred.recordLights(None, inp.rect, target, 2, lights, inp.spots, 0, cameras)
+    torch.cuda.synchronize()
+    total = target.debug.cpu().numpy().astype(np.float64)
+    acc = np.zeros_like(total)
+    for i in range(N):
+        one = (gpu.abi.SpotLightPacked * 1)(inp.spots[i])
+        deferred.recordLights(None, inp.rect, target, 2, lights, one, 0, cameras)
+        torch.cuda.synchronize()
+        acc[..., :3] += target.debug.cpu().numpy()[..., :3]
+    assert_close(total[..., :3], acc[..., :3], what="linearity")
+    deferred.cleanup()
+
+
+# ---------------------------------------------------------------------------
+# composite on identical LUTs / G-buffer / prior colour
+# ---------------------------------------------------------------------------
+def run_composite_case(gpu, W, H, elevation, spots=8, sun_shadow=None, tile=None, camera=None, lut=((512, 128), (256, 128))):
+    inp = util.Inputs(W, H, elevation_degrees=elevation, spots=spots, camera=camera)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    rows = H if tile is None else tile.local_rows
+    frame = gpu.ob.HostFrame(W, rows)
+    gpu.ob.gbuffer_fill(frame, inp.rect, tile, inp.cam, inp.synthetic.fill, threads=8)
+    gpu.ob.lights(frame, inp.rect, tile, None, inp.cam, inp.dirs, 2, 1, inp.spots, spots, threads=8)
+    prior = frame.color.copy()
+    (tw, th), (sw, sh) = lut
+    tlut = gpu.ob.transmittance_lut(inp.atm, tw, th, threads=8)
+    slut = gpu.ob.skyview_lut(inp.atm, inp.cam, tlut, sw, sh, threads=8)
+    shadow_host, keep = None, []
+    images = (gpu.abi.Image * 1)()
+    if sun_shadow is not None:
+        images[0] = gpu.ob.host_image(sun_shadow, gpu.abi.SZG_FORMAT_D32_SFLOAT)
+        shadow_host = gpu.abi.ShadowMaps(1, 0, C.cast(images, C.POINTER(gpu.abi.Image)))
+    gpu.ob.composite(frame, inp.rect, tile, shadow_host, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=8)
+
+    target = gpu.pl.SceneTexture(W, rows, debug=True)
+    target.color.copy_(torch.from_numpy(prior.view(np.int16)))
+    target.depth.copy_(torch.from_numpy(frame.depth))
+    deferred = gpu.pl.DeferredShadingPipeline((W, rows), max_spot_lights=1, max_shadow_maps=1)
+    deferred.upload_gbuffer(frame.planes())
+    if sun_shadow is not None:
+        t = torch.from_numpy(sun_shadow).cuda()
+        keep.append(t)
+        deferred.setShadowMap(0, t)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(tw, th), skyview_extent=(sw, sh))
+    sky.upload_lut(sky.transmittanceLUT(), tlut)
+    sky.upload_lut(sky.skyviewLUT(), slut)
+    sky.recordComposite(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights,
+                        tile=tile)
+    torch.cuda.synchronize()
+    got = target.debug.cpu().numpy()
+    got_q = target.color_numpy()
+    deferred.cleanup()
+    sky.destroy()
+    return got, got_q, frame
+
+
+@pytest.mark.parametrize("elevation", [70.0, 5.0, -3.0])
+def test_composite_matches_oracle(gpu, elevation):
+    got, got_q, frame = run_composite_case(gpu, 192, 108, elevation)
+    worst = assert_close(got, frame.debug, what=f"composite elev {elevation}")
+    assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+    print(f"composite elev {elevation}: worst/tol {worst:.3f}")
+
+
+def test_composite_ragged_extent_and_small_luts(gpu):
+    got, got_q, frame = run_composite_case(gpu, 70, 37, 20.0, lut=((256, 64), (128, 64)))
+    assert_close(got, frame.debug, what="composite 70x37")
+
+
+def test_composite_with_sun_shadow_map(gpu):
+    rng = np.random.default_rng(7)
+    shadow = rng.random((96, 96), dtype=np.float32)
+    got, got_q, frame = run_composite_case(gpu, 160, 90, 40.0, sun_shadow=shadow)
+    assert_close(got, frame.debug, what="composite with sun shadow map")
+
+
+def test_composite_camera_looking_down_and_up(gpu):
+    """Sky rays that hit the ground (sampleGround path) and a zenith-facing view."""
+    from syzygy_amd import scene
+
+    for pitch in (0.9, -0.9):
+        cam = scene.default_camera()
+        cam.cameraPosition[:] = [0.0, -300.0, -13.0]
+        cam.eulerAngles[:] = [pitch, 0.0, 0.3]
+        got, got_q, frame = run_composite_case(gpu, 128, 72, 30.0, camera=cam)
+        assert_close(got, frame.debug, what=f"composite pitch {pitch}")
+
+
+# ---------------------------------------------------------------------------
+# whole frame, every pass on the GPU (LUTs, fill, lights, composite chained)
+# ---------------------------------------------------------------------------
+def render_gpu(gpu, inp, tile=None, lut=((512, 128), (512, 256)), debug=True):
+    cameras, atmospheres, lights = staged(gpu, inp)
+    rows = inp.height if tile is None else tile.local_rows
+    target = gpu.pl.SceneTexture(inp.width, rows, debug=debug)
+    deferred = gpu.pl.DeferredShadingPipeline((inp.width, rows), max_spot_lights=max(inp.spot_count, 1), max_shadow_maps=0)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=lut[0], skyview_extent=lut[1])
+    deferred.recordDrawCommands(None, inp.rect, target, 1, lights, inp.spots if inp.spot_count else None, 0, cameras,
+                                inp.synthetic.fill, tile=tile)
+    sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0,
+                           lights, tile=tile)
+    torch.cuda.synchronize()
+    out = (target.debug.cpu().numpy() if debug else None, target.color_numpy())
+    deferred.cleanup()
+    sky.destroy()
+    return out
+
+
+def render_oracle(gpu, inp, lut=((512, 128), (512, 256))):
+    frame = gpu.ob.HostFrame(inp.width, inp.height)
+    gpu.ob.gbuffer_fill(frame, inp.rect, None, inp.cam, inp.synthetic.fill, threads=8)
+    gpu.ob.lights(frame, inp.rect, None, None, inp.cam, inp.dirs, 2, 1, inp.spots, inp.spot_count, threads=8)
+    tlut = gpu.ob.transmittance_lut(inp.atm, lut[0][0], lut[0][1], threads=8)
+    slut = gpu.ob.skyview_lut(inp.atm, inp.cam, tlut, lut[1][0], lut[1][1], threads=8)
+    gpu.ob.composite(frame, inp.rect, None, None, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=8)
+    return frame
+
+
+@pytest.mark.parametrize("elevation", [70.0, 5.0, -3.0])
+def test_full_frame_chain_matches_oracle(gpu, elevation):
+    """End to end: GPU LUTs feed the GPU composite. The LUT-ratio terms of the march are
+    ill-conditioned (1 - T_a/T_b with T_a ~ T_b), so last-bit differences in the GPU's own
+    transmittance LUT are amplified; the bound here is 1 UNORM16 LSB on the final image and
+    1e-3 relative on the fp32 value (per-pass parity on identical inputs is the 1e-4 test)."""
+    inp = util.Inputs(240, 136, elevation_degrees=elevation, spots=16)
+    got, got_q = render_gpu(gpu, inp)
+    frame = render_oracle(gpu, inp)
+    lsb = np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32))
+    rel = util.rel_err(got[..., :3], frame.debug[..., :3], util.ATOL_COLOR)
+    print(f"chain elev {elevation}: max LSB diff {lsb.max()}, max rel {rel.max():.3e}, "
+          f"frac within 1e-4: {(rel <= RTOL).mean():.5f}")
+    assert lsb.max() <= 1
+    assert rel.max() <= 1e-3
+
+
+# ---------------------------------------------------------------------------
+# row tiling (multi-GPU partition): every rank's tile equals its rows of the whole frame
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("nranks,block_rows", [(2, 8), (3, 4), (8, 16)])
+def test_rowtiles_equal_full_frame_bit_exact(gpu, nranks, block_rows):
+    W, H = 160, 100
+    inp = util.Inputs(W, H, elevation_degrees=25.0, spots=8)
+    full_dbg, full_q = render_gpu(gpu, inp, lut=((256, 64), (128, 64)))
+    gathered = []
+    max_rows = 0
+    for rank in range(nranks):
+        tile = util.rowtile(H, block_rows, rank, nranks)
+        dbg, q = render_gpu(gpu, inp, tile=tile, lut=((256, 64), (128, 64)))
+        rows = util.global_rows(H, block_rows, rank, nranks)
+        assert len(rows) == tile.local_rows
+        assert (q == full_q[rows]).all()
+        assert (dbg.view(np.uint32) == full_dbg[rows].view(np.uint32)).all()
+        gathered.append(q)
+        max_rows = max(max_rows, tile.local_rows)
+    # compose kernel: the gather buffer (rank-major, padded to the largest tile) -> full image
+    from syzygy_amd import lib
+    from syzygy_amd._lib import check
+
+    stride_rows = max_rows
+    buf = np.zeros((nranks, stride_rows, W, 4), np.uint16)
+    for r, q in enumerate(gathered):
+        buf[r, : q.shape[0]] = q
+    d_buf = torch.from_numpy(buf.view(np.int16)).cuda()
+    d_out = torch.zeros((H, W, 4), dtype=torch.int16, device="cuda")
+    im = gpu.abi.Image(d_out.data_ptr(), W, H, W * 8, gpu.abi.SZG_FORMAT_RGBA16_UNORM)
+    check(lib().szg_compose_rowtiles(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(d_buf.data_ptr()),
+                                     stride_rows * W * 8, nranks, block_rows, C.byref(im), W, H))
+    torch.cuda.synchronize()
+    assert (d_out.cpu().numpy().view(np.uint16) == full_q).all()
+
+
+def test_empty_draw_rect_is_a_no_op(gpu):
+    inp = util.Inputs(32, 32, spots=1)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    target = gpu.pl.SceneTexture(32, 32)
+    target.color.fill_(1234)
+    deferred = gpu.pl.DeferredShadingPipeline((32, 32), max_spot_lights=1, max_shadow_maps=0)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(64, 16), skyview_extent=(64, 32))
+    empty = gpu.pl.rect(0, 0)
+    deferred.recordDrawCommands(None, empty, target, 1, lights, inp.spots, 0, cameras, inp.synthetic.fill)
+    sky.recordComposite(None, target, empty, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    assert (target.color.cpu().numpy() == 1234).all()
+    deferred.cleanup()
+    sky.destroy()
+
+
+def test_undersized_target_is_rejected(gpu):
+    inp = util.Inputs(64, 64, spots=1)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    target = gpu.pl.SceneTexture(32, 32)
+    deferred = gpu.pl.DeferredShadingPipeline((64, 64), max_spot_lights=1, max_shadow_maps=0)
+    from syzygy_amd import SzgError
+
+    with pytest.raises(SzgError):
+        deferred.recordLights(None, inp.rect, target, 1, lights, inp.spots, 0, cameras)
+    deferred.cleanup()
+
+
+# ---------------------------------------------------------------------------
+# BASELINE full sizes through size-independent properties
+# ---------------------------------------------------------------------------
+def test_4k_frame_properties(gpu):
+    """3840x2160, 64 spots (BASELINE config 3): deterministic, finite, alpha opaque, and a
+    64-row band equals the oracle's render of the same rows."""
+    W, H = 3840, 2160
+    inp = util.Inputs(W, H, elevation_degrees=35.0, spots=64)
+    dbg1, q1 = render_gpu(gpu, inp, lut=((512, 128), (2048, 1024)))
+    dbg2, q2 = render_gpu(gpu, inp, lut=((512, 128), (2048, 1024)))
+    assert (q1 == q2).all(), "non-deterministic output"
+    assert np.isfinite(dbg1).all()
+    assert (q1[..., 3] == 65535).all()
+    sky = q1[: H // 4]
+    assert sky[..., 2].mean() > sky[..., 0].mean(), "daytime sky should be blue"
+
+    # oracle on a band of rows that crosses the horizon, via the row-tile mechanism
+    # (contiguous tiling = one block per rank)
+    band_rows = 24
+    nranks = H // band_rows
+    rank = int(0.42 * nranks)
+    tile = util.rowtile(H, band_rows, rank, nranks)
+    assert tile.local_rows == band_rows
+    frame = gpu.ob.HostFrame(W, band_rows)
+    gpu.ob.gbuffer_fill(frame, inp.rect, tile, inp.cam, inp.synthetic.fill, threads=16)
+    gpu.ob.lights(frame, inp.rect, tile, None, inp.cam, inp.dirs, 2, 1, inp.spots, 64, threads=16)
+    tlut = gpu.ob.transmittance_lut(inp.atm, 512, 128, threads=16)
+    # only the GPU's own sky-view LUT is available at full size in reasonable time: use a
+    # GPU-produced LUT for BOTH sides so that this compares the 4K composite + lights only
+    cameras, atmospheres, lights = staged(gpu, inp)
+    skyp = gpu.pl.SkyViewComputePipeline.create()
+    skyp.upload_lut(skyp.transmittanceLUT(), tlut)
+    skyp.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    torch.cuda.synchronize()
+    slut = skyp.download_lut(skyp.skyviewLUT())
+    skyp.destroy()
+    gpu.ob.composite(frame, inp.rect, tile, None, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=16)
+    rows = util.global_rows(H, band_rows, rank, nranks)
+    lsb = np.abs(q1[rows].astype(np.int32) - frame.color.astype(np.int32))
+    assert lsb.max() <= 1, lsb.max()
