@@ -17,8 +17,9 @@
 //
 // Numerics: every GLSL operation is evaluated in fp32 in the order written in
 // the shader; compile with -O2 -ffp-contract=off (no FMA contraction, no
-// fast-math). Built-ins use the correctly rounded fp32 libm functions (expf,
-// powf, sinf, cosf, asinf, acosf, sqrtf). Sampler semantics are SURVEY
+// fast-math). The implementation-defined GLSL built-ins (exp, pow, sin, cos,
+// asin, acos) are the pinned fp32 algorithms of include/szg/fpmath.h, or libm
+// with -DSZG_ORACLE_LIBM (see below); sqrt and / are IEEE correctly rounded. Sampler semantics are SURVEY
 // Appendix A: fp32 bilinear with clamp-to-edge, nearest clamp-to-edge, nearest
 // clamp-to-border(0); UNORM16 store = RTE(clamp(x,0,1)*65535).
 //
@@ -26,6 +27,26 @@
 // =============================================================================
 
 #include "szg/abi.h"
+
+// GLSL built-ins: by default the pinned fp32 algorithms of szg/fpmath.h (so that oracle
+// and GPU kernels are reproducible bit for bit); with -DSZG_ORACLE_LIBM the correctly
+// rounded libm functions instead (an independent cross-check, tests/test_oracle.py).
+#ifdef SZG_ORACLE_LIBM
+#define GL_EXP expf
+#define GL_POW powf
+#define GL_SIN sinf
+#define GL_COS cosf
+#define GL_ASIN asinf
+#define GL_ACOS acosf
+#else
+#include "szg/fpmath.h"
+#define GL_EXP szg_expf
+#define GL_POW szg_powf
+#define GL_SIN szg_sinf
+#define GL_COS szg_cosf
+#define GL_ASIN szg_asinf
+#define GL_ACOS szg_acosf
+#endif
 
 #include <algorithm>
 #include <chrono>
@@ -104,8 +125,8 @@ inline float smoothstep(float e0, float e1, float x)
     float const t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
     return t * t * (3.0f - 2.0f * t);
 }
-inline vec3 exp3(vec3 v) { return {expf(v.x), expf(v.y), expf(v.z)}; }
-inline vec3 pow3(vec3 v, float e) { return {powf(v.x, e), powf(v.y, e), powf(v.z, e)}; }
+inline vec3 exp3(vec3 v) { return {GL_EXP(v.x), GL_EXP(v.y), GL_EXP(v.z)}; }
+inline vec3 pow3(vec3 v, float e) { return {GL_POW(v.x, e), GL_POW(v.y, e), GL_POW(v.z, e)}; }
 
 struct mat4
 {
@@ -451,8 +472,8 @@ vec3 sampleTransmittanceLUT_RadiusMu(const TransmittanceLUT& LUT, const Atmosphe
 // common.glinl:145-172
 vec3 sampleTransmittanceLUT_Sun(const TransmittanceLUT& LUT, const Atmosphere& atmosphere, float radius, float cos_sunZenith)
 {
-    float const sin_sunRadius = sinf(atmosphere.sunAngularRadius);
-    float const cos_sunRadius = cosf(atmosphere.sunAngularRadius);
+    float const sin_sunRadius = GL_SIN(atmosphere.sunAngularRadius);
+    float const cos_sunRadius = GL_COS(atmosphere.sunAngularRadius);
     float const sin_horizonZenith = atmosphere.planetRadiusMm / radius;
     float const cos_horizonZenith = -safeSqrt(1.0f - sin_horizonZenith * sin_horizonZenith);
     vec3 const transmittanceThroughAtmosphere = sampleTransmittanceLUT_RadiusMu(LUT, atmosphere, radius, cos_sunZenith);
@@ -462,7 +483,7 @@ vec3 sampleTransmittanceLUT_Sun(const TransmittanceLUT& LUT, const Atmosphere& a
 }
 
 // common.glinl:174-177
-inline float densityExponential(float altitude, float densityScale) { return expf(-altitude / densityScale); }
+inline float densityExponential(float altitude, float densityScale) { return GL_EXP(-altitude / densityScale); }
 // common.glinl:180
 inline float densityTent(float altitude_km) { return fmaxf(0.0f, 1.0f - fabsf(altitude_km - 25.0f) / 15.0f); }
 
@@ -545,7 +566,7 @@ inline float phaseMie(float cosine, float g)
 {
     float const scalar = 3.0f / (8.0f * PI);
     float const numerator = (1.0f - g * g) * (1.0f + cosine * cosine);
-    float const denominator = (2.0f + g * g) * powf(1.0f + g * g - 2.0f * g * cosine, 1.5f);
+    float const denominator = (2.0f + g * g) * GL_POW(1.0f + g * g - 2.0f * g * cosine, 1.5f);
     return scalar * numerator / denominator;
 }
 
@@ -722,17 +743,17 @@ vec4 transmittance_texel(const Atmosphere& atmosphere, int W, int H, int tx, int
 void uv_to_azimuthElevation(const Atmosphere& atmosphere, float radius, vec2 uv, float& azimuth, float& elevation)
 {
     float const sinHorizonZenith = atmosphere.planetRadiusMm / radius;
-    float const horizonZenith = PI - asinf(sinHorizonZenith);
+    float const horizonZenith = PI - GL_ASIN(sinHorizonZenith);
 
     float const cosineViewLightProjected = (uv.x - 0.5f) * 2.0f;
     vec2 const lightDirectionProjected = normalize(vec2{-atmosphere.incidentDirectionSun.x, -atmosphere.incidentDirectionSun.z});
 
-    float azimuthSun = asinf(lightDirectionProjected.x);
+    float azimuthSun = GL_ASIN(lightDirectionProjected.x);
     if (lightDirectionProjected.y < 0.0f)
     {
         azimuthSun = PI - azimuthSun;
     }
-    azimuth = acosf(clampf(cosineViewLightProjected, -1.0f, 1.0f)) + azimuthSun;
+    azimuth = GL_ACOS(clampf(cosineViewLightProjected, -1.0f, 1.0f)) + azimuthSun;
 
     float viewZenith;
     if (uv.y < 0.5f)
@@ -815,7 +836,7 @@ PBRTexel convertPBRProperties(const GBufferTexel& gbuffer)
     t.subscatteringColor = {gbuffer.diffuseColor.x, gbuffer.diffuseColor.y, gbuffer.diffuseColor.z};
     t.normalReflectance = mix(dialectricReflectence, metallicReflectence, metallic);
     t.occlusion = gbuffer.occlusionRoughnessMetallic.x;
-    t.specularPower = powf(specularPower, 1.0f - gbuffer.occlusionRoughnessMetallic.y);
+    t.specularPower = GL_POW(specularPower, 1.0f - gbuffer.occlusionRoughnessMetallic.y);
     t.metallic = metallic;
     return t;
 }
@@ -824,7 +845,7 @@ PBRTexel convertPBRProperties(const GBufferTexel& gbuffer)
 vec3 computeFresnel(const PBRTexel& material, vec3 lightOutgoing, vec3 viewOutgoing)
 {
     vec3 const halfwayDirection = normalize(lightOutgoing + viewOutgoing);
-    float const p = powf(1.0f - clampf(dot(halfwayDirection, lightOutgoing), 0.0f, 1.0f), 5.0f);
+    float const p = GL_POW(1.0f - clampf(dot(halfwayDirection, lightOutgoing), 0.0f, 1.0f), 5.0f);
     return material.normalReflectance + (vec3(1.0f) - material.normalReflectance) * p;
 }
 // pbrFunctions.glinl:34-39
@@ -834,7 +855,7 @@ vec3 specularBRDF(const PBRTexel& material, vec3 lightOutgoing, vec3 viewOutgoin
 {
     vec3 const halfwayDirection = normalize(lightOutgoing + viewOutgoing);
     float const specularPower = material.specularPower;
-    float const microfacetDistribution = powf(clampf(dot(halfwayDirection, material.normal), 0.0f, 1.0f), specularPower);
+    float const microfacetDistribution = GL_POW(clampf(dot(halfwayDirection, material.normal), 0.0f, 1.0f), specularPower);
     float const normalizationTerm = (specularPower + 2.0f) / 8.0f;
     return vec3(normalizationTerm * microfacetDistribution);
 }
@@ -958,10 +979,10 @@ vec3 sampleMap_Direction(const CompositeContext& c, vec3 position, vec3 directio
     const Atmosphere& atmosphere = c.atmosphere;
     vec3 const normalized = normalize(direction);
     float const sinHorizonZenith = atmosphere.planetRadiusMm / length(position);
-    float const horizonZenith = PI - asinf(sinHorizonZenith);
+    float const horizonZenith = PI - GL_ASIN(sinHorizonZenith);
     float const cosViewZenith = normalized.y;
     float const cosHorizonZenith = -safeSqrt(1.0f - sinHorizonZenith * sinHorizonZenith);
-    float const viewZenith = acosf(normalized.y);
+    float const viewZenith = GL_ACOS(normalized.y);
     float u, v;
     if (cosViewZenith > cosHorizonZenith)
     {
@@ -1035,12 +1056,12 @@ vec3 sampleGround(const CompositeContext& c, vec3 origin, vec3 direction, float 
     vec3 const viewDirection = -direction;
     vec3 const halfwayDirection = normalize(lightDirection + viewDirection);
     float const specularPower = 160.0f;
-    float const microfacetAttenuation = powf(clampf(dot(halfwayDirection, surfaceNormal), 0.0f, 1.0f), specularPower);
+    float const microfacetAttenuation = GL_POW(clampf(dot(halfwayDirection, surfaceNormal), 0.0f, 1.0f), specularPower);
     float const normalizationTerm = (specularPower + 2.0f) / 8.0f;
     vec3 const specular = vec3(normalizationTerm * microfacetAttenuation);
     vec3 const diffuse = vec3(0.4f) / PI;
     vec3 const fresnel = vec3(0.04f) + (vec3(1.0f) - vec3(0.04f)) *
-                                           powf(1.0f - clampf(dot(halfwayDirection, lightDirection), 0.0f, 1.0f), 5.0f);
+                                           GL_POW(1.0f - clampf(dot(halfwayDirection, lightDirection), 0.0f, 1.0f), 5.0f);
     vec3 const albedo = mix(diffuse, specular, fresnel);
     vec3 const transmittanceToSun = sampleTransmittanceLUT_Ray(c.transmittance_LUT, atmosphere, surfacePosition, lightDirection);
     vec3 const surfaceLuminance = transmittanceToSun * albedo * clampf(dot(surfaceNormal, lightDirection), 0.0f, 1.0f);
@@ -1236,7 +1257,7 @@ void oracle_skyview_lut(const szg_atmosphere_packed* atmospheres, uint32_t atmos
                 float azimuth, elevation;
                 uv_to_azimuthElevation(atmosphere, length(origin), uv, azimuth, elevation);
                 vec3 const direction =
-                    normalize(vec3{sinf(azimuth) * cosf(elevation), sinf(elevation), cosf(azimuth) * cosf(elevation)});
+                    normalize(vec3{GL_SIN(azimuth) * GL_COS(elevation), GL_SIN(elevation), GL_COS(azimuth) * GL_COS(elevation)});
 
                 float distanceThroughAtmosphere;
                 raycastAtmosphere(atmosphere, origin, direction, distanceThroughAtmosphere);

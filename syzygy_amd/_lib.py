@@ -30,6 +30,10 @@ def lib():
                 f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(or `make -C syzygy_amd/csrc`). There is no CPU fallback for this path."
             )
+        # torch bundles its own HIP runtime; import it first so that this library binds to the
+        # SAME runtime instance (device pointers and streams are shared with torch).
+        import torch  # noqa: F401
+
         handle = ctypes.CDLL(path)
         abi.bind(handle, abi.ABI_FUNCTIONS)
         abi.bind(handle, abi.HOST_FUNCTIONS)

@@ -36,10 +36,10 @@ SZG_DEV V3 sampleMapDirection(const SkyLut& S, const Atm& a, V3 position, V3 dir
     float const PI = 3.141592653589793f;
     V3 const normalized = normalize(direction);
     float const sinHorizonZenith = a.planetRadius / length(position);
-    float const horizonZenith = PI - asinf(sinHorizonZenith);
+    float const horizonZenith = PI - szg_asinf(sinHorizonZenith);
     float const cosViewZenith = normalized.y;
     float const cosHorizonZenith = -safeSqrt(1.0f - sinHorizonZenith * sinHorizonZenith);
-    float const viewZenith = acosf(normalized.y);
+    float const viewZenith = szg_acosf(normalized.y);
     float v;
     if (cosViewZenith > cosHorizonZenith)
     {
@@ -92,12 +92,12 @@ SZG_DEV V3 groundSurfaceTerm(const TLut& L, const Atm& a, V3 origin, V3 directio
     V3 const viewDirection = -direction;
     V3 const h = normalize(lightDirection + viewDirection);
     float const specularPower = 160.0f;
-    float const microfacet = powf(clampf(dot(h, surfaceNormal), 0.0f, 1.0f), specularPower);
+    float const microfacet = szg_powf(clampf(dot(h, surfaceNormal), 0.0f, 1.0f), specularPower);
     float const normalization = (specularPower + 2.0f) / 8.0f;
     V3 const specular = splat(normalization * microfacet);
     V3 const diffuse = splat(0.4f) / PI;
     V3 const fresnel =
-        splat(0.04f) + (splat(1.0f) - splat(0.04f)) * powf(1.0f - clampf(dot(h, lightDirection), 0.0f, 1.0f), 5.0f);
+        splat(0.04f) + (splat(1.0f) - splat(0.04f)) * szg_powf(1.0f - clampf(dot(h, lightDirection), 0.0f, 1.0f), 5.0f);
     V3 const albedo = mix(diffuse, specular, fresnel);
     V3 const transmittanceToSun = sampleT_Ray(L, a, surfacePosition, lightDirection);
     V3 const surfaceLuminance = (transmittanceToSun * albedo) * clampf(dot(surfaceNormal, lightDirection), 0.0f, 1.0f);
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(256) void k_composite(szg_image color, szg_image de
     }
     V3 const luminance = transfer * a.sunIntensitySpectrum;
     V3 const pre = luminance * 10.0f + surfaceLuminance;
-    V3 const out = mk3(powf(pre.x, 1.2f), powf(pre.y, 1.2f), powf(pre.z, 1.2f));
+    V3 const out = mk3(szg_powf(pre.x, 1.2f), szg_powf(pre.y, 1.2f), szg_powf(pre.z, 1.2f));
     row_ptr<uint2>(color, y)[x] = pack_unorm16x4(out.x, out.y, out.z, 1.0f);
     if (debug.data != nullptr)
     {

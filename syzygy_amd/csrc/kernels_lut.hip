@@ -63,9 +63,9 @@ __global__ __launch_bounds__(64) void k_transmittance(const szg_atmosphere_packe
         V3 const position = origin + t * direction;
         float const altitude = length(position) - a.planetRadius;
         Extinction const e = sampleExtinction(a, altitude);
-        T.x = T.x * expf(ndt * e.extinction.x);
-        T.y = T.y * expf(ndt * e.extinction.y);
-        T.z = T.z * expf(ndt * e.extinction.z);
+        T.x = T.x * szg_expf(ndt * e.extinction.x);
+        T.y = T.y * szg_expf(ndt * e.extinction.y);
+        T.z = T.z * szg_expf(ndt * e.extinction.z);
     }
     lut[id] = make_float4(T.x, T.y, T.z, 1.0f);
 }
@@ -102,15 +102,15 @@ __global__ __launch_bounds__(256) void k_skyview(const szg_atmosphere_packed* __
     // uv_to_azimuthElevation, skyview_LUT.comp:51-89
     float const radius = length(origin);
     float const sinHorizonZenith = a.planetRadius / radius;
-    float const horizonZenith = PI - asinf(sinHorizonZenith);
+    float const horizonZenith = PI - szg_asinf(sinHorizonZenith);
     float const cosineViewLightProjected = (u - 0.5f) * 2.0f;
     V2 const lightDirectionProjected = normalize(V2{-a.incidentDirectionSun.x, -a.incidentDirectionSun.z});
-    float azimuthSun = asinf(lightDirectionProjected.x);
+    float azimuthSun = szg_asinf(lightDirectionProjected.x);
     if (lightDirectionProjected.y < 0.0f)
     {
         azimuthSun = PI - azimuthSun;
     }
-    float const azimuth = acosf(clampf(cosineViewLightProjected, -1.0f, 1.0f)) + azimuthSun;
+    float const azimuth = szg_acosf(clampf(cosineViewLightProjected, -1.0f, 1.0f)) + azimuthSun;
     float viewZenith;
     float const unnormalized_v = 2.0f * v - 1.0f;
     if (v < 0.5f)
@@ -126,8 +126,8 @@ __global__ __launch_bounds__(256) void k_skyview(const szg_atmosphere_packed* __
     float const elevation = -(viewZenith - PI / 2.0f);
 
     // skyview_LUT.comp:118-119
-    float const ce = cosf(elevation);
-    V3 const direction = normalize(mk3(sinf(azimuth) * ce, sinf(elevation), cosf(azimuth) * ce));
+    float const ce = szg_cosf(elevation);
+    V3 const direction = normalize(mk3(szg_sinf(azimuth) * ce, szg_sinf(elevation), szg_cosf(azimuth) * ce));
 
     float const distance = raycastAtmosphere(a, origin, direction);
     V3 const luminance = scatteringIntegral(L, a, origin, direction, distance);

@@ -3,7 +3,9 @@
 // Every function keeps the operation ORDER of the GLSL it implements (cited
 // per function, paths relative to the reference's shaders/ directory) so that
 // with -ffp-contract=off the +,-,*,/,sqrt results are bit-identical to a
-// straight evaluation; only exp/pow/trig come from the device math library.
+// straight evaluation; exp/pow/sin/cos/asin/acos are the pinned fp32 algorithms
+// of include/szg/fpmath.h (never the device math library), so the kernels
+// reproduce the scalar oracle bit for bit.
 // What differs from the shaders is purely structural: loop invariants are
 // hoisted into per-ray / per-light / per-atmosphere constants, images are
 // linear buffers, samplers are explicit address arithmetic.
@@ -13,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include "szg/abi.h"
+#include "szg/fpmath.h"
 
 #define SZG_DEV __device__ __forceinline__
 
@@ -214,10 +217,10 @@ struct Extinction
 };
 SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude)
 {
-    float const densityRayleigh = expf(-altitude / a.densityScaleRayleigh);
+    float const densityRayleigh = szg_expf(-altitude / a.densityScaleRayleigh);
     V3 const scatteringRayleigh = a.scatteringRayleigh * densityRayleigh;
     V3 const absorptionRayleigh = a.absorptionRayleigh * densityRayleigh;
-    float const densityMie = expf(-altitude / a.densityScaleMie);
+    float const densityMie = szg_expf(-altitude / a.densityScaleMie);
     V3 const scatteringMie = a.scatteringMie * densityMie;
     V3 const absorptionMie = a.absorptionRayleigh * densityMie;
     float const densityOzone = fmaxf(0.0f, 1.0f - fabsf(altitude * 1000.0f - 25.0f) / 15.0f);
@@ -379,7 +382,7 @@ SZG_DEV float phaseMie(float cosine, float g)
 {
     float const scalar = 3.0f / (8.0f * 3.141592653589793f);
     float const numerator = (1.0f - g * g) * (1.0f + cosine * cosine);
-    float const denominator = (2.0f + g * g) * powf(1.0f + g * g - 2.0f * g * cosine, 1.5f);
+    float const denominator = (2.0f + g * g) * szg_powf(1.0f + g * g - 2.0f * g * cosine, 1.5f);
     return scalar * numerator / denominator;
 }
 
@@ -400,8 +403,8 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     float const incidentCosine = dot(a.incidentDirectionSun, scatteringDir);
     float const pR = phaseRayleigh(incidentCosine);
     float const pM = phaseMie(incidentCosine, 0.8f);
-    float const sin_sunRadius = sinf(a.sunAngularRadius);
-    float const cos_sunRadius = cosf(a.sunAngularRadius);
+    float const sin_sunRadius = szg_sinf(a.sunAngularRadius);
+    float const cos_sunRadius = szg_cosf(a.sunAngularRadius);
 
     // stepRadiusMu invariants (common.glinl:325)
     float const mu_sunAndStep = safeSqrt(mu_sun * mu - safeSqrt((1.0f - mu_sun * mu_sun) * (1.0f - mu * mu)));
@@ -485,7 +488,7 @@ SZG_DEV Material convertPBR(V4 position, V4 normal, V4 diffuse, V4 specular, V4 
     m.metallic = orm.z;
     m.reflectance = mix(splat(0.04f), metallicReflectance, splat(m.metallic));
     m.occlusion = orm.x;
-    m.specularPower = powf(160.0f, 1.0f - orm.y);
+    m.specularPower = szg_powf(160.0f, 1.0f - orm.y);
     return m;
 }
 
@@ -495,10 +498,10 @@ SZG_DEV V3 brdfMix(const Material& m, V3 lightDir, V3 viewDir)
 {
     V3 const diffuse = m.subscattering / 3.14159265359f;
     V3 const h = normalize(lightDir + viewDir);
-    float const microfacet = powf(clampf(dot(h, m.normal), 0.0f, 1.0f), m.specularPower);
+    float const microfacet = szg_powf(clampf(dot(h, m.normal), 0.0f, 1.0f), m.specularPower);
     float const normalization = (m.specularPower + 2.0f) / 8.0f;
     V3 const specular = splat(normalization * microfacet);
-    float const p = powf(1.0f - clampf(dot(h, lightDir), 0.0f, 1.0f), 5.0f);
+    float const p = szg_powf(1.0f - clampf(dot(h, lightDir), 0.0f, 1.0f), 5.0f);
     V3 const fresnel = m.reflectance + (splat(1.0f) - m.reflectance) * p;
     return mix(diffuse, specular, fresnel);
 }
@@ -507,7 +510,7 @@ SZG_DEV V3 brdfMix(const Material& m, V3 lightDir, V3 viewDir)
 SZG_DEV V3 computeFresnel(const Material& m, V3 lightOutgoing, V3 viewOutgoing)
 {
     V3 const h = normalize(lightOutgoing + viewOutgoing);
-    float const p = powf(1.0f - clampf(dot(h, lightOutgoing), 0.0f, 1.0f), 5.0f);
+    float const p = szg_powf(1.0f - clampf(dot(h, lightOutgoing), 0.0f, 1.0f), 5.0f);
     return m.reflectance + (splat(1.0f) - m.reflectance) * p;
 }
 

@@ -328,10 +328,10 @@ def render_oracle(gpu, inp, lut=((512, 128), (512, 256))):
 
 @pytest.mark.parametrize("elevation", [70.0, 5.0, -3.0])
 def test_full_frame_chain_matches_oracle(gpu, elevation):
-    """End to end: GPU LUTs feed the GPU composite. The LUT-ratio terms of the march are
-    ill-conditioned (1 - T_a/T_b with T_a ~ T_b), so last-bit differences in the GPU's own
-    transmittance LUT are amplified; the bound here is 1 UNORM16 LSB on the final image and
-    1e-3 relative on the fp32 value (per-pass parity on identical inputs is the 1e-4 test)."""
+    """End to end: GPU LUTs feed the GPU composite (nothing is uploaded from the oracle).
+    The LUT-ratio terms of the march are ill-conditioned (1 - T_a/T_b with T_a ~ T_b), so
+    this only holds because the GLSL built-ins are pinned (include/szg/fpmath.h) and every
+    other operation is IEEE correctly rounded on both sides."""
     inp = util.Inputs(240, 136, elevation_degrees=elevation, spots=16)
     got, got_q = render_gpu(gpu, inp)
     frame = render_oracle(gpu, inp)
@@ -340,7 +340,7 @@ def test_full_frame_chain_matches_oracle(gpu, elevation):
     print(f"chain elev {elevation}: max LSB diff {lsb.max()}, max rel {rel.max():.3e}, "
           f"frac within 1e-4: {(rel <= RTOL).mean():.5f}")
     assert lsb.max() <= 1
-    assert rel.max() <= 1e-3
+    assert rel.max() <= RTOL
 
 
 # ---------------------------------------------------------------------------
@@ -355,9 +355,12 @@ def test_rowtiles_equal_full_frame_bit_exact(gpu, nranks, block_rows):
     max_rows = 0
     for rank in range(nranks):
         tile = util.rowtile(H, block_rows, rank, nranks)
-        dbg, q = render_gpu(gpu, inp, tile=tile, lut=((256, 64), (128, 64)))
         rows = util.global_rows(H, block_rows, rank, nranks)
         assert len(rows) == tile.local_rows
+        if tile.local_rows == 0:  # more ranks than row blocks: this rank holds nothing
+            gathered.append(np.zeros((0, W, 4), np.uint16))
+            continue
+        dbg, q = render_gpu(gpu, inp, tile=tile, lut=((256, 64), (128, 64)))
         assert (q == full_q[rows]).all()
         assert (dbg.view(np.uint32) == full_dbg[rows].view(np.uint32)).all()
         gathered.append(q)
