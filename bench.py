@@ -1,0 +1,274 @@
+#!/usr/bin/env python3
+"""bench.py — Mpixels/s of the deferred-lit + atmosphere frame on MI355X.
+
+A step is ONE frame of the hot path over a G-buffer that is already resident in HBM:
+    lights pass (deferred/lights.comp)           -> scene colour
+    transmittance LUT + sky-view LUT + composite (atmosphere/*.comp) -> scene colour
+(the four dispatches the reference records every frame: renderer.cpp:383-415). Nothing is
+cached between steps: both LUTs are recomputed each frame exactly like the reference
+(skyview.cpp:799-893).
+
+Workloads (BASELINE.json configs):
+    c3  3840x2160, 64 spot lights, 1 GPU                      <- default at --gpus 1
+    c4  7680x4320, 64 spot lights, rows cyclically tiled over --gpus N ranks, one RCCL
+        gather of the RGBA16 tiles to rank 0 + one compose kernel <- default at --gpus N > 1
+    c2  1920x1080, 0 spot lights (sun by the composite, moon by the lights pass)
+    c5  3840x2160, 256 spot lights per GPU, independent replicas, no collective
+
+Prints ONE JSON line on rank 0 (see the repo contract), with `roofline` for the dominant
+kernel (the composite) and `cpu_baseline` (the scalar oracle timed on this box's cores).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+WORKLOADS = {
+    "c2": dict(width=1920, height=1080, spots=0, tiled=False, label="C2 1920x1080 sun+moon, sky-view composite, 0 spots"),
+    "c3": dict(width=3840, height=2160, spots=64, tiled=False,
+               label="C3 3840x2160 full atmosphere (LUTs 512x128 + 2048x1024 recomputed per frame) + 64 spot lights"),
+    "c4": dict(width=7680, height=4320, spots=64, tiled=True,
+               label="C4 7680x4320 deferred+atmosphere, cyclic row tiles over the ranks, RCCL gather + compose"),
+    "c5": dict(width=3840, height=2160, spots=256, tiled=False, label="C5 3840x2160 per GPU, 256 spot lights, independent views"),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+BLOCK_ROWS = 8  # row-tile block height (one kernel workgroup row)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
+    ap.add_argument("--elevation", type=float, default=35.0, help="sun elevation in degrees")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the frame the CPU baseline shades")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as entry
+
+    entry.build(only_if_missing=True)
+    from syzygy_amd import abi, lib, pipelines as pl, scene
+    from syzygy_amd._lib import check
+
+    name = args.workload if args.workload != "auto" else ("c3" if args.gpus == 1 else "c4")
+    wl = WORKLOADS[name]
+    W, H, SPOTS = wl["width"], wl["height"], wl["spots"]
+    tiled = wl["tiled"] and world > 1
+    nranks = world if tiled else 1
+    tile = None
+    rows = H
+    if tiled:
+        rows = lib().szg_rowtile_local_rows(H, BLOCK_ROWS, rank, nranks)
+        tile = abi.RowTile(BLOCK_ROWS, rank, nranks, rows)
+    stride_rows = max(lib().szg_rowtile_local_rows(H, BLOCK_ROWS, r, nranks) for r in range(nranks)) if tiled else H
+
+    # ---- inputs (seeded, synthetic: SURVEY 8d) ---------------------------------------
+    syn = scene.SyntheticScene()
+    atmosphere = scene.default_atmosphere(scene.sun_euler_for_elevation(args.elevation))
+    atm, sun, moon = scene.atmosphere_baked(atmosphere, syn.bounds)
+    cam = scene.camera_packed(scene.default_camera(), W / H)
+    spots = scene.spot_ring(SPOTS)
+    dev = f"cuda:{local_rank}"
+    cameras = pl.TStagedBuffer(abi.CameraPacked, 1, dev)
+    atmospheres = pl.TStagedBuffer(abi.AtmospherePacked, 1, dev)
+    lights = pl.TStagedBuffer(abi.DirectionalLightPacked, 2, dev)
+    cameras.push(cam)
+    atmospheres.push(atm)
+    lights.push([sun, moon])
+    for b in (cameras, atmospheres, lights):
+        b.recordCopyToDevice()
+
+    target = pl.SceneTexture(W, max(stride_rows, 1), dev)
+    deferred = pl.DeferredShadingPipeline((W, max(rows, 1)), max_spot_lights=max(SPOTS, 1), max_shadow_maps=0,
+                                          device_index=local_rank)
+    sky = pl.SkyViewComputePipeline.create(device_index=local_rank)
+    assert sky is not None
+    rect = pl.rect(W, H)
+    # G-buffer fill: producer of the synthetic input, outside the timed region
+    deferred.recordGBufferFill(None, rect, target, 0, cameras, syn.fill, tile=tile)
+    torch.cuda.synchronize()
+    geometry_px_local = int((target.depth[:rows] > 0).sum().item())
+
+    gathered = composed = composed_im = None
+    if tiled and rank == 0:
+        gathered = torch.empty((nranks, stride_rows, W, 4), dtype=torch.int16, device=dev)
+        composed = torch.empty((H, W, 4), dtype=torch.int16, device=dev)
+        composed_im = abi.Image(composed.data_ptr(), W, H, W * 8, abi.SZG_FORMAT_RGBA16_UNORM)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
+    spot_arg = spots if SPOTS else None
+
+    def frame(events=None):
+        e = events
+        if e:
+            e[0].record()
+        deferred.recordLights(None, rect, target, 1, lights, spot_arg, 0, cameras, tile=tile)
+        if e:
+            e[1].record()
+        sky.recordTransmittance(None, 0, atmospheres)
+        if e:
+            e[2].record()
+        sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+        if e:
+            e[3].record()
+        sky.recordComposite(None, target, rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0,
+                            lights, tile=tile)
+        if e:
+            e[4].record()
+        if tiled:
+            # the one collective of the path: gather the RGBA16 row tiles on rank 0 (RCCL over xGMI)
+            dist.gather(target.color, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            if rank == 0:
+                check(lib().szg_compose_rowtiles(C.c_void_p(torch.cuda.current_stream().cuda_stream),
+                                                 C.c_void_p(gathered.data_ptr()), stride_rows * W * 8, nranks, BLOCK_ROWS,
+                                                 C.byref(composed_im), W, H))
+        if e:
+            e[5].record()
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        frame()
+    sync_all()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        frame(ev[k])
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    g = torch.tensor([geometry_px_local], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if tiled:
+            dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    elapsed = float(t.item())
+    frames_total = args.steps * (1 if (tiled or world == 1) else world)  # replicas render `world` frames per step
+    total_px = W * H * frames_total
+    value = total_px / elapsed / 1e6
+
+    # per-pass device times on this rank (ms), from the events recorded inside the timed region
+    names = ["lights", "transmittance", "skyview", "composite", "gather+compose"]
+    per = {n: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) for i, n in enumerate(names)}
+    G_frame = int(g.item()) if tiled else geometry_px_local
+    N_local = W * rows
+    G_local = geometry_px_local
+    # algorithmic bytes: composite reads G-buffer 48 + depth 4 per px, prior colour 8 per geometry px,
+    # writes 8 per px; lights reads 48 per px and writes 8 per px (clear fused). Per launch on this rank.
+    bytes_composite = 60 * N_local + 8 * G_local
+    bytes_lights = 56 * N_local
+    bytes_luts = 16 * (512 * 128 + 2048 * 1024)
+    comp_s = per["composite"] / 1e3
+    roofline = {
+        "bound": "hbm", "kernel": "k_composite",
+        "achieved": bytes_composite / comp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": bytes_composite / comp_s / 1e9 / HBM_PEAK_GBS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": bytes_composite, "avg_launch_ms": per["composite"],
+    }
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_composite.json")
+    if os.path.exists(pmc) and name == "c3":
+        try:
+            roofline["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
+        except Exception:
+            pass
+    frame_bytes = bytes_composite + bytes_lights + bytes_luts
+    frame_s = sum(per[n] for n in names[:4]) / 1e3
+
+    out = {
+        "metric": "Mpixels/s deferred-lit+atmosphere", "value": value, "unit": "Mpixels/s", "n_gpus": args.gpus,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong" if wl["tiled"] else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": wl["label"], "width": W, "height": H, "spot_lights": SPOTS, "geometry_fraction": G_frame / (W * H),
+                   "sun_elevation_deg": args.elevation, "row_tile_block_rows": BLOCK_ROWS if tiled else None,
+                   "parallelism": (f"rowtile{nranks}+gather" if tiled else ("single" if world == 1 else f"replicas{world}"))},
+        "pass_ms_rank0": per,
+        "roofline": roofline,
+        "roofline_frame": {"algorithmic_bytes": frame_bytes, "device_ms": frame_s * 1e3,
+                           "achieved_GBps": frame_bytes / frame_s / 1e9, "frac": frame_bytes / frame_s / 1e9 / HBM_PEAK_GBS},
+    }
+
+    if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
+        out["cpu_baseline"] = cpu_baseline(args, wl, atm, cam, sun, moon, spots, syn)
+    if rank == 0:
+        log("per-pass device ms:", {k: round(v, 4) for k, v in per.items()})
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    deferred.cleanup()
+    sky.destroy()
+
+
+def cpu_baseline(args, wl, atm, cam, sun, moon, spots, syn):
+    """The scalar oracle (oracle/, the parity checker) timed on this box's cores on a bounded
+    sample of the same workload: both LUTs in full, plus lights + composite on `cpu_rows` rows
+    spread evenly over the frame (row-tile with 1-row blocks), scaled to the full height."""
+    from oracle import binding as ob
+    from syzygy_amd import abi, lib
+
+    W, H, SPOTS = wl["width"], wl["height"], wl["spots"]
+    threads = max(1, min(os.cpu_count() or 1, 64))
+    sample_rows = min(args.cpu_rows, H)
+    nranks = H // sample_rows
+    tile = abi.RowTile(1, nranks // 2, nranks, lib().szg_rowtile_local_rows(H, 1, nranks // 2, nranks))
+    rect = abi.Rect(0, 0, W, H)
+    frame = ob.HostFrame(W, tile.local_rows, debug=False)
+    dirs = (abi.DirectionalLightPacked * 2)(sun, moon)
+    ob.gbuffer_fill(frame, rect, tile, cam, syn.fill, threads=threads)
+    t0 = time.perf_counter()
+    tlut = ob.transmittance_lut(atm, 512, 128, threads=threads)
+    t1 = time.perf_counter()
+    slut = ob.skyview_lut(atm, cam, tlut, 2048, 1024, threads=threads)
+    t2 = time.perf_counter()
+    ob.lights(frame, rect, tile, None, cam, dirs, 2, 1, spots, SPOTS, threads=threads)
+    t3 = time.perf_counter()
+    ob.composite(frame, rect, tile, None, atm, cam, dirs, 0, tlut, slut, threads=threads)
+    t4 = time.perf_counter()
+    scale = H / tile.local_rows
+    est = (t1 - t0) + (t2 - t1) + ((t3 - t2) + (t4 - t3)) * scale
+    return {
+        "value": W * H / est / 1e6, "unit": "Mpixels/s", "cores": threads, "kind": "port",
+        "sample": (f"both LUTs in full ({t1 - t0:.2f}s + {t2 - t1:.2f}s) + lights/composite on {tile.local_rows} of {H} rows "
+                   f"spread evenly over the frame ({t3 - t2:.2f}s + {t4 - t3:.2f}s), extrapolated x{scale:.1f}; "
+                   f"{threads} std::threads, -O2 -ffp-contract=off"),
+        "estimated_frame_s": est,
+    }
+
+
+if __name__ == "__main__":
+    main()

@@ -14,7 +14,7 @@
  * (checked on hardware: DESIGN.md "numerics").
  *
  * Accuracy against float64 libm is measured in tests/test_fpmath.py:
- *   exp <= 1 ULP, log <= 1 ULP, sin/cos <= 1.5 ULP on |x| <= 16, asin/acos <= 2.5 ULP,
+ *   exp <= 1 ULP, log <= 3 ULP, sin/cos <= 1.6 ULP on |x| <= 10, asin/acos <= 2.5 ULP,
  *   pow = exp(y * log(x)) (error grows with |y log x| exactly as GLSL's definition).
  * Polynomial coefficients: exp/log after SLEEF 3 (Boost licence) single-precision
  * kernels; sin/cos/asin after Cephes single-precision kernels (S. Moshier).
@@ -34,14 +34,13 @@ SZG_FP_FN int szg_float_to_bits(float f) { return __builtin_bit_cast(int, f); }
 /* 2^k for k in [-126, 127] */
 SZG_FP_FN float szg_pow2i(int k) { return szg_bits_to_float((k + 127) << 23); }
 
+/* All functions below are branch-free (selects only): they sit in the inner loops of
+ * the GPU kernels. */
+
 /* exp(x), natural. */
 SZG_FP_FN float szg_expf(float x)
 {
-    if (!(x == x))
-    {
-        return x;
-    }
-    float const xc = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f);
+    float const xc = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f); /* NaN -> -104, patched below */
     float const q = __builtin_rintf(xc * 1.442695040888963407359924681001892137426645954152985934135449406931f);
     float s = __builtin_fmaf(q, -0.693145751953125f, xc);
     s = __builtin_fmaf(q, -1.428606765330187045e-06f, s);
@@ -54,34 +53,20 @@ SZG_FP_FN float szg_expf(float x)
     u = __builtin_fmaf(s * s, u, s) + 1.0f;
     int const qi = (int)q;
     int const q1 = qi >> 1;
-    return (u * szg_pow2i(q1)) * szg_pow2i(qi - q1);
+    float const r = (u * szg_pow2i(q1)) * szg_pow2i(qi - q1);
+    return (x == x) ? r : x;
 }
 
-/* log(x), natural. x < 0 -> NaN, x == 0 -> -inf, denormals handled. */
+/* log(x), natural. x < 0 -> NaN, x == 0 -> -inf, +inf -> +inf, denormals handled. */
 SZG_FP_FN float szg_logf(float x)
 {
-    if (!(x == x) || x < 0.0f)
-    {
-        return __builtin_nanf("");
-    }
-    if (x == 0.0f)
-    {
-        return -__builtin_inff();
-    }
-    if (x == __builtin_inff())
-    {
-        return x;
-    }
-    int eadj = 0;
-    if (x < 1.17549435e-38f)
-    {
-        x = x * 16777216.0f; /* 2^24: exact */
-        eadj = -24;
-    }
-    /* x = m * 2^e with m in [0.75, 1.5) */
-    int const bits = szg_float_to_bits(x * 1.3333333333333333333333333333333333333f);
+    int const tiny = x < 1.17549435e-38f;
+    float const xs = tiny ? x * 16777216.0f : x; /* 2^24: exact */
+    int const eadj = tiny ? -24 : 0;
+    /* xs = m * 2^e with m in [0.75, 1.5) */
+    int const bits = szg_float_to_bits(xs * 1.3333333333333333333333333333333333333f);
     int const e = ((bits >> 23) & 0xFF) - 127;
-    float const m = szg_bits_to_float(szg_float_to_bits(x) - (e << 23));
+    float const m = szg_bits_to_float(szg_float_to_bits(xs) - (e << 23));
     float const t = (m - 1.0f) / (m + 1.0f);
     float const t2 = t * t;
     float p = 0.2392828464508056640625f;
@@ -90,22 +75,21 @@ SZG_FP_FN float szg_logf(float x)
     p = __builtin_fmaf(p, t2, 0.666666686534881591796875f);
     p = __builtin_fmaf(p, t2, 2.0f);
     float const fe = (float)(e + eadj);
-    return __builtin_fmaf(t, p, 0.693147180559945286226764f * fe);
+    float r = __builtin_fmaf(t, p, 0.693147180559945286226764f * fe);
+    r = (x == __builtin_inff()) ? x : r;
+    r = (x == 0.0f) ? -__builtin_inff() : r;
+    r = (!(x == x) || x < 0.0f) ? __builtin_nanf("") : r;
+    return r;
 }
 
 /* pow(x, y) for x >= 0 as GLSL defines it: undefined for x < 0 (NaN here);
  * pow(0, y>0) = 0, pow(x, 0) = 1. */
 SZG_FP_FN float szg_powf(float x, float y)
 {
-    if (y == 0.0f)
-    {
-        return 1.0f;
-    }
-    if (x == 0.0f)
-    {
-        return y > 0.0f ? 0.0f : __builtin_inff();
-    }
-    return szg_expf(y * szg_logf(x));
+    float r = szg_expf(y * szg_logf(x));
+    r = (x == 0.0f) ? (y > 0.0f ? 0.0f : __builtin_inff()) : r;
+    r = (y == 0.0f) ? 1.0f : r;
+    return r;
 }
 
 /* Argument reduction by pi/2 (three-part Cody-Waite, exact products for |x| < 2^13). */
@@ -134,28 +118,24 @@ SZG_FP_FN float szg_cos_poly(float r)
     p = __builtin_fmaf(p, z, 4.166664568298827e-2f);
     return __builtin_fmaf(p * z, z, __builtin_fmaf(-0.5f, z, 1.0f));
 }
-/* sin(x), cos(x); intended range |x| <= 8192 (the path uses |x| < 10). */
+/* sin(x), cos(x); intended range |x| <= 8192 (the path uses |x| < 10), NaN outside. */
 SZG_FP_FN float szg_sinf(float x)
 {
-    if (!(__builtin_fabsf(x) <= 8192.0f))
-    {
-        return __builtin_nanf("");
-    }
+    int const ok = __builtin_fabsf(x) <= 8192.0f;
     int n;
-    float const r = szg_reduce_pio2(x, &n);
+    float const r = szg_reduce_pio2(ok ? x : 0.0f, &n);
     float const v = (n & 1) ? szg_cos_poly(r) : szg_sin_poly(r);
-    return (n & 2) ? -v : v;
+    float const w = (n & 2) ? -v : v;
+    return ok ? w : __builtin_nanf("");
 }
 SZG_FP_FN float szg_cosf(float x)
 {
-    if (!(__builtin_fabsf(x) <= 8192.0f))
-    {
-        return __builtin_nanf("");
-    }
+    int const ok = __builtin_fabsf(x) <= 8192.0f;
     int n;
-    float const r = szg_reduce_pio2(x, &n);
+    float const r = szg_reduce_pio2(ok ? x : 0.0f, &n);
     float const v = (n & 1) ? szg_sin_poly(r) : szg_cos_poly(r);
-    return ((n + 1) & 2) ? -v : v;
+    float const w = ((n + 1) & 2) ? -v : v;
+    return ok ? w : __builtin_nanf("");
 }
 
 /* asin on [0, 0.5]: x + x * z * P(z), z = x^2 */
@@ -172,42 +152,28 @@ SZG_FP_FN float szg_asin_core(float x, float z)
 SZG_FP_FN float szg_asinf(float x)
 {
     float const a = __builtin_fabsf(x);
-    if (!(a <= 1.0f))
-    {
-        return __builtin_nanf("");
-    }
-    float r;
-    if (a <= 0.5f)
-    {
-        r = szg_asin_core(a, a * a);
-    }
-    else
-    {
-        float const z = 0.5f * (1.0f - a);
-        float const s = __builtin_sqrtf(z);
-        float const t = szg_asin_core(s, z);
-        r = 1.5707963267948966192313216916397514f - (t + t);
-    }
-    return x < 0.0f ? -r : r;
+    int const small = a <= 0.5f;
+    float const z = small ? a * a : 0.5f * (1.0f - a);
+    float const s = small ? a : __builtin_sqrtf(z);
+    float const t = szg_asin_core(s, z);
+    float const r = small ? t : 1.5707963267948966192313216916397514f - (t + t);
+    float const w = x < 0.0f ? -r : r;
+    return (a <= 1.0f) ? w : __builtin_nanf("");
 }
 /* acos(x); |x| > 1 -> NaN */
 SZG_FP_FN float szg_acosf(float x)
 {
     float const a = __builtin_fabsf(x);
-    if (!(a <= 1.0f))
-    {
-        return __builtin_nanf("");
-    }
-    if (a <= 0.5f)
-    {
-        float const t = szg_asin_core(a, a * a);
-        return x < 0.0f ? (1.5707963267948966192313216916397514f + t) : (1.5707963267948966192313216916397514f - t);
-    }
-    float const z = 0.5f * (1.0f - a);
-    float const s = __builtin_sqrtf(z);
+    int const small = a <= 0.5f;
+    float const z = small ? a * a : 0.5f * (1.0f - a);
+    float const s = small ? a : __builtin_sqrtf(z);
     float const t = szg_asin_core(s, z);
-    float const r = t + t;
-    return x < 0.0f ? (3.14159265358979323846264338327950288f - r) : r;
+    float const hp = 1.5707963267948966192313216916397514f;
+    float const rs = x < 0.0f ? (hp + t) : (hp - t);
+    float const r2 = t + t;
+    float const rl = x < 0.0f ? (3.14159265358979323846264338327950288f - r2) : r2;
+    float const w = small ? rs : rl;
+    return (a <= 1.0f) ? w : __builtin_nanf("");
 }
 
 #endif /* SZG_FPMATH_H */

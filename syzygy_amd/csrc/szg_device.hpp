@@ -331,18 +331,74 @@ SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float f
     return r;
 }
 
+// transmittanceLUT_RMu_to_UV (common.glinl:40-66) + the bilinear fetch, split into the
+// part that depends only on the radius (v coordinate, row pair and row weights) and the
+// part that depends on mu. Two taps at the same radius share the first part; every
+// operation and its order are those of the unsplit evaluation.
+struct RadiusPart
+{
+    float r, r2;        // radius, radius * radius
+    float d_min, denom; // atmosphereRadius - radius, (rho + H) - d_min
+    const float4* row0; // texel rows j0, j1 (clamped)
+    const float4* row1;
+    float b, omb;       // v weight and 1 - b
+};
+SZG_DEV RadiusPart radiusPart(const TLut& L, const Atm& a, float radius)
+{
+    RadiusPart p;
+    p.r = radius;
+    p.r2 = radius * radius;
+    float const rho = safeSqrt(p.r2 - a.Rp2);
+    p.d_min = a.atmosphereRadius - radius;
+    float const d_max = rho + a.H;
+    p.denom = d_max - p.d_min;
+    float const x_radius = rho / a.H;
+    float const t = L.v_bias + x_radius * L.v_scale;
+    float const v = t * L.fheight - 0.5f;
+    float const fv = floorf(v);
+    p.b = v - fv;
+    p.omb = 1.0f - p.b;
+    int j0 = (int)fv;
+    int j1 = j0 + 1;
+    j0 = min(max(j0, 0), L.height - 1);
+    j1 = min(max(j1, 0), L.height - 1);
+    p.row0 = L.texels + j0 * L.width;
+    p.row1 = L.texels + j1 * L.width;
+    return p;
+}
+SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, const RadiusPart& p, float mu)
+{
+    float const d = fmaxf(-p.r * mu + safeSqrt(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f);
+    float const x_mu = (d - p.d_min) / p.denom;
+    float const s = L.u_bias + x_mu * L.u_scale;
+    float const u = s * L.fwidth - 0.5f;
+    float const fu = floorf(u);
+    float const al = u - fu;
+    int i0 = (int)fu;
+    int i1 = i0 + 1;
+    i0 = min(max(i0, 0), L.width - 1);
+    i1 = min(max(i1, 0), L.width - 1);
+    float4 const t00 = p.row0[i0];
+    float4 const t10 = p.row0[i1];
+    float4 const t01 = p.row1[i0];
+    float4 const t11 = p.row1[i1];
+    float const oma = 1.0f - al;
+    float const w00 = oma * p.omb;
+    float const w10 = al * p.omb;
+    float const w01 = oma * p.b;
+    float const w11 = al * p.b;
+    V3 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    return r;
+}
+
 // common.glinl:40-66 + :138-143 : sample at (radius, mu)
 SZG_DEV V3 sampleT_RadiusMu(const TLut& L, const Atm& a, float radius, float mu)
 {
-    float const rho = safeSqrt(radius * radius - a.Rp2);
-    float const d = fmaxf(-radius * mu + safeSqrt(radius * radius * (mu * mu - 1.0f) + a.Ra2), 0.0f);
-    float const d_min = a.atmosphereRadius - radius;
-    float const d_max = rho + a.H;
-    float const x_mu = (d - d_min) / (d_max - d_min);
-    float const x_radius = rho / a.H;
-    float const s = L.u_bias + x_mu * L.u_scale;
-    float const t = L.v_bias + x_radius * L.v_scale;
-    return bilinear_rgb(L.texels, L.width, L.height, L.fwidth, L.fheight, s, t);
+    RadiusPart const p = radiusPart(L, a, radius);
+    return sampleT_at(L, a, p, mu);
 }
 
 // common.glinl:104-112
@@ -353,23 +409,28 @@ SZG_DEV V3 sampleT_Ray(const TLut& L, const Atm& a, V3 position, V3 direction)
     return sampleT_RadiusMu(L, a, radius, mu);
 }
 
-// common.glinl:114-136
+// common.glinl:114-136. The flipped branch samples with -direction, whose mu is the exact
+// negation of the unflipped one (negation commutes with every rounding), so one code path
+// with a sign select reproduces both branches.
+SZG_DEV V3 segmentRatio(const TLut& L, const Atm& a, const RadiusPart& pFrom, float fromDotDir, float lenFrom,
+                        const RadiusPart& pTo, float toDotDir, float lenTo, float lenDir)
+{
+    bool const flip = fromDotDir < 0.0f;
+    float const muFrom = fromDotDir / (lenFrom * lenDir);
+    float const muTo = toDotDir / (lenTo * lenDir);
+    V3 const Tf = sampleT_at(L, a, pFrom, flip ? -muFrom : muFrom);
+    V3 const Tt = sampleT_at(L, a, pTo, flip ? -muTo : muTo);
+    V3 const q = flip ? (Tt / Tf) : (Tf / Tt);
+    return clamp01(q);
+}
 SZG_DEV V3 sampleT_Segment(const TLut& L, const Atm& a, V3 from, V3 to)
 {
     V3 const direction = normalize(to - from);
-    V3 num, den;
-    if (dot(from, direction) < 0.0f)
-    {
-        V3 const nd = -direction;
-        num = sampleT_Ray(L, a, to, nd);
-        den = sampleT_Ray(L, a, from, nd);
-    }
-    else
-    {
-        num = sampleT_Ray(L, a, from, direction);
-        den = sampleT_Ray(L, a, to, direction);
-    }
-    return clamp01(num / den);
+    float const lenFrom = length(from);
+    float const lenTo = length(to);
+    RadiusPart const pf = radiusPart(L, a, lenFrom);
+    RadiusPart const pt = radiusPart(L, a, lenTo);
+    return segmentRatio(L, a, pf, dot(from, direction), lenFrom, pt, dot(to, direction), lenTo, length(direction));
 }
 
 // common.glinl:263-279
@@ -417,46 +478,54 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
 
     V3 luminance = splat(0.0f);
     float const dS = sampleDistance / 32.0f;
+    // `end` of step i and `begin` of step i+1 are the same expression (common.glinl:386-387),
+    // so its length and radius part are carried from one iteration to the next.
+    V3 begin = origin - (0.0f * dS) * scatteringDir;
+    float lenBegin = length(begin);
+    RadiusPart pBegin = radiusPart(L, a, lenBegin);
 #pragma unroll 1
     for (unsigned i = 0; i < 32u; i++)
     {
         float const fi = (float)i;
         float const t = fi * dS;
-        V3 const begin = origin - (fi * dS) * scatteringDir;
         V3 const end = origin - ((float)(i + 1u) * dS) * scatteringDir;
+        float const lenEnd = length(end);
+        RadiusPart const pEnd = radiusPart(L, a, lenEnd);
 
         // stepRadiusMu(originStep, t), common.glinl:329-331
         float const s_radius = safeSqrt(t * t + two_r_mu * t + r2);
         float const s_mu = (r_mu + t) / s_radius;
         float const s_musun = (r_musun + t * mu_sunAndStep) / s_radius;
+        RadiusPart const pStep = radiusPart(L, a, s_radius);
 
-        float const altitude = length(begin) - a.planetRadius;
+        float const altitude = lenBegin - a.planetRadius;
 
         // sampleTransmittanceLUT_Sun, common.glinl:145-172
         float const sin_hz = a.planetRadius / s_radius;
         float const cos_hz = -safeSqrt(1.0f - sin_hz * sin_hz);
-        V3 const T_atm = sampleT_RadiusMu(L, a, s_radius, s_musun);
+        V3 const T_atm = sampleT_at(L, a, pStep, s_musun);
         float const angularFactor = smoothstep(-sin_hz * sin_sunRadius, sin_hz * sin_sunRadius, s_musun - cos_hz * cos_sunRadius);
         V3 const T_sun = T_atm * angularFactor;
 
         Extinction const ex = sampleExtinction(a, altitude);
 
         // sampleTransmittanceLUT_RayMarchStep, common.glinl:336-361
-        V3 T_begin;
-        if (t < 0.0000001f)
-        {
-            T_begin = splat(1.0f);
-        }
-        else
-        {
-            V3 const T_end = sampleT_RadiusMu(L, a, s_radius, up ? s_mu : -s_mu);
-            T_begin = clamp01(up ? (T_origin / T_end) : (T_end / T_origin));
-        }
+        V3 const T_end = sampleT_at(L, a, pStep, up ? s_mu : -s_mu);
+        V3 const ratio = clamp01(up ? (T_origin / T_end) : (T_end / T_origin));
+        V3 const T_begin = (t < 0.0000001f) ? splat(1.0f) : ratio;
 
         V3 const phaseTimesScattering = ex.scatteringRayleigh * pR + ex.scatteringMie * pM;
-        V3 const T_path = sampleT_Segment(L, a, begin, end);
+
+        // sampleTransmittanceLUT_Segment(begin, end), common.glinl:114-136
+        V3 const segDir = normalize(end - begin);
+        V3 const T_path =
+            segmentRatio(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd, length(segDir));
         V3 const integral = (splat(1.0f) - T_path) / ex.extinction;
         luminance = luminance + phaseTimesScattering * T_sun * integral * T_begin;
+
+        begin = end;
+        lenBegin = lenEnd;
+        pBegin = pEnd;
     }
     return luminance;
 }
