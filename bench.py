@@ -77,20 +77,16 @@ def main():
     import __graft_entry__ as entry
 
     entry.build(only_if_missing=True)
-    from syzygy_amd import abi, lib, pipelines as pl, scene
-    from syzygy_amd._lib import check
+    from syzygy_amd import abi, lib, pipelines as pl, rowtile, scene
 
     name = args.workload if args.workload != "auto" else ("c3" if args.gpus == 1 else "c4")
     wl = WORKLOADS[name]
     W, H, SPOTS = wl["width"], wl["height"], wl["spots"]
     tiled = wl["tiled"] and world > 1
     nranks = world if tiled else 1
-    tile = None
-    rows = H
-    if tiled:
-        rows = lib().szg_rowtile_local_rows(H, BLOCK_ROWS, rank, nranks)
-        tile = abi.RowTile(BLOCK_ROWS, rank, nranks, rows)
-    stride_rows = max(lib().szg_rowtile_local_rows(H, BLOCK_ROWS, r, nranks) for r in range(nranks)) if tiled else H
+    tile = rowtile.make_tile(H, rank, nranks, BLOCK_ROWS)
+    rows = tile.local_rows if tile is not None else H
+    stride_rows = rowtile.stride_rows(H, nranks, BLOCK_ROWS)
 
     # ---- inputs (seeded, synthetic: SURVEY 8d) ---------------------------------------
     syn = scene.SyntheticScene()
@@ -119,11 +115,10 @@ def main():
     torch.cuda.synchronize()
     geometry_px_local = int((target.depth[:rows] > 0).sum().item())
 
-    gathered = composed = composed_im = None
+    gathered = composed = None
     if tiled and rank == 0:
         gathered = torch.empty((nranks, stride_rows, W, 4), dtype=torch.int16, device=dev)
         composed = torch.empty((H, W, 4), dtype=torch.int16, device=dev)
-        composed_im = abi.Image(composed.data_ptr(), W, H, W * 8, abi.SZG_FORMAT_RGBA16_UNORM)
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
     spot_arg = spots if SPOTS else None
@@ -147,11 +142,9 @@ def main():
             e[4].record()
         if tiled:
             # the one collective of the path: gather the RGBA16 row tiles on rank 0 (RCCL over xGMI)
-            dist.gather(target.color, list(gathered.unbind(0)) if rank == 0 else None, dst=0)
+            rowtile.gather_tiles(target.color, rank, nranks, gathered=gathered)
             if rank == 0:
-                check(lib().szg_compose_rowtiles(C.c_void_p(torch.cuda.current_stream().cuda_stream),
-                                                 C.c_void_p(gathered.data_ptr()), stride_rows * W * 8, nranks, BLOCK_ROWS,
-                                                 C.byref(composed_im), W, H))
+                rowtile.compose(gathered, H, nranks, BLOCK_ROWS, out=composed)
         if e:
             e[5].record()
 

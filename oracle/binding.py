@@ -13,6 +13,7 @@ from syzygy_amd import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
+_LIBM = None
 
 VP = C.c_void_p
 U32 = C.c_uint32
@@ -24,13 +25,12 @@ def build():
     subprocess.run(["make", "-C", _HERE, "-s"], check=True)
 
 
-def lib():
-    global _LIB
-    if _LIB is None:
-        path = os.path.join(_HERE, "libszg_oracle.so")
+def _load(name):
+        path = os.path.join(_HERE, name)
         if not os.path.exists(path):
             build()
         h = C.CDLL(path)
+        h.oracle_builtin_eval.argtypes = [C.c_int, FP, FP, FP, C.c_size_t]
         h.oracle_abi_version.restype = C.c_int
         h.oracle_transmittance_lut.argtypes = [P(abi.AtmospherePacked), U32, U32, U32, FP, C.c_int]
         h.oracle_transmittance_texel.argtypes = [P(abi.AtmospherePacked), U32, U32, U32, U32, FP]
@@ -54,8 +54,45 @@ def lib():
         h.oracle_unorm16_store.restype = C.c_uint16
         h.oracle_unorm16_store.argtypes = [C.c_float]
         assert h.oracle_abi_version() == abi.SZG_ABI_VERSION
-        _LIB = h
+        return h
+
+
+def lib():
+    """The oracle with the GLSL built-ins pinned to include/szg/fpmath.h (the parity checker)."""
+    global _LIB
+    if _LIB is None:
+        _LIB = _load("libszg_oracle.so")
     return _LIB
+
+
+def lib_libm():
+    """The same oracle with libm built-ins: an independent cross-check of the pinned one."""
+    global _LIBM
+    if _LIBM is None:
+        _LIBM = _load("libszg_oracle_libm.so")
+    return _LIBM
+
+
+class use_libm:
+    """Context manager: route the module-level helpers to the libm build."""
+
+    def __enter__(self):
+        global _LIB
+        self._saved = lib()
+        _LIB = lib_libm()
+
+    def __exit__(self, *a):
+        global _LIB
+        _LIB = self._saved
+        return False
+
+
+def builtin_eval(fn, x, y=None, libm=False):
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y if y is not None else np.zeros_like(x), np.float32)
+    out = np.empty_like(x)
+    (lib_libm() if libm else lib()).oracle_builtin_eval(fn, fptr(x), fptr(y), fptr(out), x.size)
+    return out
 
 
 def fptr(a):

@@ -1589,6 +1589,25 @@ void oracle_gbuffer_fill(const szg_scene_texture* scene, szg_rect drawRect, cons
     });
 }
 
+// The GLSL built-ins as this build evaluates them (pinned fpmath, or libm with
+// -DSZG_ORACLE_LIBM), vectorised for the accuracy tests. fn: 0 exp, 1 pow(x, y), 2 sin,
+// 3 cos, 4 asin, 5 acos.
+void oracle_builtin_eval(int fn, const float* x, const float* y, float* out, size_t n)
+{
+    for (size_t i = 0; i < n; i++)
+    {
+        switch (fn)
+        {
+        case 0: out[i] = GL_EXP(x[i]); break;
+        case 1: out[i] = GL_POW(x[i], y[i]); break;
+        case 2: out[i] = GL_SIN(x[i]); break;
+        case 3: out[i] = GL_COS(x[i]); break;
+        case 4: out[i] = GL_ASIN(x[i]); break;
+        default: out[i] = GL_ACOS(x[i]); break;
+        }
+    }
+}
+
 // fp16 helpers exposed so tests can cross-check them against numpy.float16
 uint16_t oracle_float_to_half(float f) { return float_to_half(f); }
 float oracle_half_to_float(uint16_t h) { return half_to_float(h); }

@@ -1,0 +1,80 @@
+"""Row tiling of the framebuffer across the GPUs of one node + the single gather of the
+composed image (BASELINE north_star). No reference counterpart: the reference is
+single-GPU. Pixels are independent, so there is no halo and no other collective.
+
+Rows are cut into blocks of `block_rows`; block b belongs to rank b % nranks (cyclic), which
+balances the cheap sky rows at the top of a frame against the expensive geometry rows at the
+bottom. A rank stores only its own rows, packed; include/szg/abi.h `szg_rowtile` gives the
+local -> global row map the kernels use for the camera rays (camera.comp:324 uses global pixel
+coordinates and the full draw extent).
+
+One process per GPU; the gather is `torch.distributed.gather` (RCCL over xGMI when the backend
+is "nccl", plain TCP with "gloo"): N-1 point-to-point streams into rank 0, then one HBM-bound
+row scatter (`szg_compose_rowtiles`) on rank 0.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import abi
+from ._lib import check, lib
+
+DEFAULT_BLOCK_ROWS = 8
+
+
+def local_rows(height, rank, nranks, block_rows=DEFAULT_BLOCK_ROWS):
+    return int(lib().szg_rowtile_local_rows(int(height), int(block_rows), int(rank), int(nranks)))
+
+
+def make_tile(height, rank, nranks, block_rows=DEFAULT_BLOCK_ROWS):
+    """abi.RowTile for `rank`, or None when there is a single rank (whole frame)."""
+    if nranks <= 1:
+        return None
+    return abi.RowTile(int(block_rows), int(rank), int(nranks), local_rows(height, rank, nranks, block_rows))
+
+
+def stride_rows(height, nranks, block_rows=DEFAULT_BLOCK_ROWS):
+    """Rows of the largest tile: every rank's colour buffer is padded to this so that the gather
+    moves equal-sized tensors."""
+    return max(local_rows(height, r, nranks, block_rows) for r in range(max(nranks, 1)))
+
+
+def global_rows(height, rank, nranks, block_rows=DEFAULT_BLOCK_ROWS):
+    """Global row index of each local row of `rank` (host mirror of szg_rowtile's map)."""
+    if nranks <= 1:
+        return np.arange(height, dtype=np.int64)
+    nblocks = (height + block_rows - 1) // block_rows
+    out = [np.arange(b * block_rows, min(height, (b + 1) * block_rows), dtype=np.int64) for b in range(rank, nblocks, nranks)]
+    return np.concatenate(out) if out else np.zeros((0,), np.int64)
+
+
+def gather_tiles(local_color, rank, nranks, gathered=None, dst=0, group=None):
+    """The one collective of the path. `local_color`: [stride_rows, W, 4] int16 (RGBA16 UNORM bits)
+    on every rank; `gathered`: [nranks, stride_rows, W, 4] on `dst` (allocated if None). Returns
+    `gathered` on dst, None elsewhere."""
+    # RCCL and gloo have no 16-bit integer type: move the tiles as bytes
+    send = local_color.contiguous().view(torch.uint8)
+    if rank == dst:
+        if gathered is None:
+            gathered = torch.empty((nranks,) + tuple(local_color.shape), dtype=local_color.dtype, device=local_color.device)
+        dist.gather(send, list(gathered.view(torch.uint8).unbind(0)), dst=dst, group=group)
+        return gathered
+    dist.gather(send, None, dst=dst, group=group)
+    return None
+
+
+def compose(gathered, height, nranks, block_rows=DEFAULT_BLOCK_ROWS, out=None, stream=None):
+    """Scatter the gathered tiles' rows into the full-frame RGBA16 image on the GPU."""
+    if not gathered.is_cuda:
+        raise RuntimeError("compose() runs the HIP row-scatter kernel and needs CUDA tensors; there is no CPU fallback")
+    n, srows, width, _ = gathered.shape
+    assert n == nranks and gathered.is_contiguous()
+    if out is None:
+        out = torch.empty((height, width, 4), dtype=gathered.dtype, device=gathered.device)
+    im = abi.Image(out.data_ptr(), width, height, width * 8, abi.SZG_FORMAT_RGBA16_UNORM)
+    handle = stream if stream is not None else torch.cuda.current_stream().cuda_stream
+    check(lib().szg_compose_rowtiles(C.c_void_p(handle), C.c_void_p(gathered.data_ptr()), srows * width * 8, nranks, block_rows,
+                                     C.byref(im), width, height))
+    return out

@@ -1,0 +1,91 @@
+"""The C-ABI library loads on a machine without a GPU, exports every symbol that
+include/szg/abi.h and include/szg/host.h declare, keeps the reference's struct sizes,
+and fails loudly (no CPU fallback) when asked to create a pipeline without a device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from syzygy_amd import abi, lib, library_path
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols(header):
+    text = open(os.path.join(ROOT, "include", "szg", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(szg_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_is_in_tree():
+    assert os.path.exists(library_path())
+    assert library_path().startswith(ROOT)
+
+
+@pytest.mark.parametrize("header,table", [("abi.h", abi.ABI_FUNCTIONS), ("host.h", abi.HOST_FUNCTIONS)])
+def test_every_declared_symbol_is_exported_and_bound(header, table):
+    handle = C.CDLL(library_path())
+    names = declared_symbols(header)
+    assert names, header
+    for name in names:
+        assert hasattr(handle, name), f"{name} declared in {header} but not exported"
+        assert name in table, f"{name} declared in {header} but has no ctypes signature"
+    for name in table:
+        assert name in names, f"{name} bound in Python but not declared in {header}"
+
+
+def test_struct_sizes_match_the_reference():
+    # renderer/gputypes.hpp:36, :72, :90, :115
+    assert C.sizeof(abi.CameraPacked) == 416
+    assert C.sizeof(abi.AtmospherePacked) == 128
+    assert C.sizeof(abi.DirectionalLightPacked) == 176
+    assert C.sizeof(abi.SpotLightPacked) == 192
+    # std430 offsets used by the shaders (types/atmosphere.glinl)
+    assert abi.AtmospherePacked.incidentDirectionSun.offset == 64
+    assert abi.AtmospherePacked.sunIntensitySpectrum.offset == 112
+    assert abi.AtmospherePacked.sunAngularRadius.offset == 124
+    assert abi.CameraPacked.inverseProjection.offset == 64
+    assert abi.CameraPacked.rotation.offset == 256
+    assert abi.CameraPacked.position.offset == 400
+    assert abi.SpotLightPacked.position.offset == 160
+    assert abi.SpotLightPacked.falloffDistance.offset == 184
+
+
+def test_abi_version():
+    assert lib().szg_abi_version() == abi.SZG_ABI_VERSION
+
+
+def test_rowtile_local_rows_partition_the_frame():
+    f = lib().szg_rowtile_local_rows
+    for height in (1, 7, 100, 1080, 2160, 4320):
+        for block in (1, 5, 8, 16):
+            for nranks in (1, 2, 3, 4, 8):
+                rows = [f(height, block, r, nranks) for r in range(nranks)]
+                assert sum(rows) == height, (height, block, nranks, rows)
+                assert max(rows) - min(rows) <= block
+    assert f(100, 0, 0, 2) == 0 and f(100, 8, 2, 2) == 0
+
+
+def test_no_cpu_fallback_without_a_device():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    handle = C.c_void_p()
+    desc = abi.SkyviewDesc(512, 128, 2048, 1024, 0, 0)
+    status = lib().szg_skyview_create(C.byref(handle), C.byref(desc), 0)
+    assert status == -2 and not handle.value
+    assert b"no CPU fallback" in lib().szg_last_error()
+    ddesc = abi.DeferredDesc(64, 64, 4, 4, 0, 0)
+    assert lib().szg_deferred_create(C.byref(handle), C.byref(ddesc), 0) == -2
+    from syzygy_amd import pipelines
+
+    assert pipelines.SkyViewComputePipeline.create() is None  # skyview.cpp:713-740: nullptr on failure
+
+
+def test_null_arguments_are_rejected():
+    assert lib().szg_skyview_create(None, None, 0) == -1
+    assert lib().szg_deferred_create(None, None, 0) == -1
+    assert lib().szg_compose_rowtiles(None, None, 0, 1, 1, None, 0, 0) == -1
+    lib().szg_skyview_destroy(None)
+    lib().szg_deferred_destroy(None)
