@@ -10,8 +10,9 @@ cached between steps: both LUTs are recomputed each frame exactly like the refer
 
 Workloads (BASELINE.json configs):
     c3  3840x2160, 64 spot lights, 1 GPU                      <- default at --gpus 1
-    c4  7680x4320, 64 spot lights, rows cyclically tiled over --gpus N ranks, one RCCL
-        gather of the RGBA16 tiles to rank 0 + one compose kernel <- default at --gpus N > 1
+    c4  7680x4320, 64 spot lights, rows cyclically tiled over --gpus N ranks; sky-view LUT rows
+        sharded over the ranks + one all-gather; one RCCL gather of the RGBA16 tiles to rank 0 +
+        one compose kernel                                       <- default at --gpus N > 1
     c2  1920x1080, 0 spot lights (sun by the composite, moon by the lights pass)
     c5  3840x2160, 256 spot lights per GPU, independent replicas, no collective
 
@@ -120,6 +121,7 @@ def main():
         gathered = torch.empty((nranks, stride_rows, W, 4), dtype=torch.int16, device=dev)
         composed = torch.empty((H, W, 4), dtype=torch.int16, device=dev)
 
+    sky_lut = sky.skyviewLUT_tensor() if tiled else None
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
     spot_arg = spots if SPOTS else None
 
@@ -133,7 +135,13 @@ def main():
         sky.recordTransmittance(None, 0, atmospheres)
         if e:
             e[2].record()
-        sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+        if tiled:
+            # every rank computes 1/N of the sky-view LUT rows, then one all-gather (texels are independent)
+            b, en = rowtile.lut_rows(sky_lut.shape[0], rank, nranks)
+            sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, b, en)
+            rowtile.allgather_lut(sky_lut, rank, nranks)
+        else:
+            sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
         if e:
             e[3].record()
         sky.recordComposite(None, target, rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0,

@@ -313,6 +313,13 @@ int szg_skyview_record_transmittance(szg_skyview_t* p, void* stream, uint32_t at
 int szg_skyview_record_skyview_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
                                    const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
                                    const szg_camera_packed* d_cameras);
+/* Multi-GPU extension (no reference counterpart): compute only texel rows [row_begin, row_end) of the
+ * sky-view LUT, so that N ranks each produce 1/N of it and exchange the slices with one all-gather
+ * (texels are independent: skyview_LUT.comp:91-128 reads only the transmittance LUT). The full
+ * transmittance LUT must have been recorded on this pipeline first. */
+int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                        const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                                        const szg_camera_packed* d_cameras, uint32_t row_begin, uint32_t row_end);
 int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture,
                                  szg_rect draw_rect, const szg_rowtile* tile, const szg_gbuffer* gbuffer,
                                  const szg_shadowmaps* shadow_maps, uint32_t atmosphere_index,

@@ -279,6 +279,7 @@ ABI_FUNCTIONS = {
     ),
     "szg_skyview_record_transmittance": (C.c_int, [VP, VP, U32, VP]),
     "szg_skyview_record_skyview_lut": (C.c_int, [VP, VP, U32, VP, U32, VP]),
+    "szg_skyview_record_skyview_lut_rows": (C.c_int, [VP, VP, U32, VP, U32, VP, U32, U32]),
     "szg_skyview_record_composite": (
         C.c_int,
         [VP, VP, P(SceneTexture), Rect, P(RowTile), P(GBuffer), P(ShadowMaps), U32, VP, U32, VP, U32, VP],

@@ -11,16 +11,63 @@
 
 namespace szg
 {
-// One texel per lane, 64-lane workgroups: 512x128 texels = 1024 workgroups, so
-// the 500-step serial loop lands on every SIMD of the chip (1024 SIMDs).
-__global__ __launch_bounds__(64) void k_transmittance(const szg_atmosphere_packed* __restrict__ atmospheres,
+// transmittance_LUT.comp:93-103. The 500 factors exp(-|dt| * extinction_i) are independent; only their
+// product is sequential. 8 lanes share a texel: lane `sub` evaluates steps 8k + sub, then the running product is
+// passed along the 8 lanes in ascending step order, i.e. (((1 * f0) * f1) * f2) ... exactly as the reference loop
+// does; it ends up in the group's last lane. Steps >= 500
+// contribute the factor 1.0, which is exact. This turns 1 wave per SIMD with a 500-deep serial chain into 8 waves
+// per SIMD with a 63-deep one.
+// v_mov_b32 with a DPP control (0x100 + n = row_shl:n, 0x110 + n = row_shr:n, rows of 16 lanes); the compiler
+// folds it into the consuming v_mul_f32.
+template <int CTRL> SZG_DEV float dpp(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+
+constexpr int T_LANES = 8;
+constexpr int T_STEPS = 500; // transmittance_LUT.comp:53
+
+template <bool LEAN> SZG_DEV V3 transmittanceProduct(const Atm& a, V3 origin, V3 direction, float distance, float ndt, int sub)
+{
+    V3 T = splat(1.0f);
+    float const rcp500 = rcpN(500.0f);
+#pragma unroll 1
+    for (int k = 0; k < (T_STEPS + T_LANES - 1) / T_LANES; k++)
+    {
+        int const i = k * T_LANES + sub;
+        float const t = divRX<LEAN>(distance * ((float)i + 0.5f), 500.0f, rcp500);
+        V3 const position = origin + t * direction;
+        float const altitude = sqrtX<LEAN>(dot(position, position)) - a.planetRadius;
+        Extinction const e = sampleExtinction<LEAN>(a, altitude);
+        bool const valid = i < T_STEPS;
+        float const fx = valid ? szg_expf(ndt * e.extinction.x) : 1.0f;
+        float const fy = valid ? szg_expf(ndt * e.extinction.y) : 1.0f;
+        float const fz = valid ? szg_expf(ndt * e.extinction.z) : 1.0f;
+        // Ordered product along the 8 lanes of the group with DPP (no LDS): position 0 takes the running
+        // product from position 7 (row_shl:7), then position j takes position j-1's value (row_shr:1) and
+        // multiplies its own factor. After 8 steps position 7 holds (((P * f0) * f1) ... * f7).
+        T.x = dpp<0x107>(T.x) * fx;
+        T.y = dpp<0x107>(T.y) * fy;
+        T.z = dpp<0x107>(T.z) * fz;
+#pragma unroll
+        for (int j = 1; j < T_LANES; j++)
+        {
+            T.x = dpp<0x111>(T.x) * fx;
+            T.y = dpp<0x111>(T.y) * fy;
+            T.z = dpp<0x111>(T.z) * fz;
+        }
+    }
+    return T;
+}
+
+// 256-thread workgroups = 32 texels x 8 lanes. 512x128 texels -> 2048 workgroups, 8 waves per SIMD.
+__global__ __launch_bounds__(256) void k_transmittance(const szg_atmosphere_packed* __restrict__ atmospheres,
                                                       unsigned atmosphereIndex, float4* __restrict__ lut, int W, int H)
 {
-    int const id = (int)(blockIdx.x * 64u + threadIdx.x);
-    if (id >= W * H)
-    {
-        return;
-    }
+    int const sub = (int)(threadIdx.x & (unsigned)(T_LANES - 1));
+    int const idRaw = (int)((blockIdx.x * 256u + threadIdx.x) / (unsigned)T_LANES);
+    bool const inRangeTexel = idRaw < W * H;
+    int const id = inRangeTexel ? idRaw : (W * H - 1); // out-of-range lanes shadow the last texel, never store
     int const tx = id % W;
     int const ty = id / W;
     Atm const a = load_atm(atmospheres + atmosphereIndex);
@@ -47,27 +94,21 @@ __global__ __launch_bounds__(64) void k_transmittance(const szg_atmosphere_packe
     V3 const direction = mk3(sqrtf(1.0f - mu * mu), mu, 0.0f);
 
     float t0 = 0.0f, t1 = 0.0f;
-    if (!raySphere(origin, direction, a.atmosphereRadius, t0, t1))
-    {
-        lut[id] = make_float4(1.0f, 1.0f, 1.0f, 1.0f);
-        return;
-    }
-    float const distance = t1;
+    bool const hit = raySphere(origin, direction, a.atmosphereRadius, t0, t1);
+    // transmittance_LUT.comp:85-89: a miss stores 1; such a texel still walks the loop below with harmless
+    // operands (the 8 lanes of a texel agree on `hit`, but shuffles need every lane of the wave in the loop)
+    float const distance = hit ? t1 : 0.0f;
     float const dt = distance / 500.0f;
     float const ndt = -fabsf(dt);
-    V3 T = splat(1.0f);
-#pragma unroll 2
-    for (int i = 0; i < 500; i++)
+    // lean exact ops (szg_device.hpp) when the atmosphere block and this ray are in their domain; the flag is
+    // wave-uniform so that the loop body exists once per wave
+    bool const lean = __all(a.lean && inRange(radius, 0.9f * a.planetRadius, 0x1p30f) && inRange(distance, 0.0f, 0x1p30f));
+    V3 const T = lean ? transmittanceProduct<true>(a, origin, direction, distance, ndt, sub)
+                      : transmittanceProduct<false>(a, origin, direction, distance, ndt, sub);
+    if (inRangeTexel && sub == T_LANES - 1)
     {
-        float const t = distance * ((float)i + 0.5f) / 500.0f;
-        V3 const position = origin + t * direction;
-        float const altitude = length(position) - a.planetRadius;
-        Extinction const e = sampleExtinction(a, altitude);
-        T.x = T.x * szg_expf(ndt * e.extinction.x);
-        T.y = T.y * szg_expf(ndt * e.extinction.y);
-        T.z = T.z * szg_expf(ndt * e.extinction.z);
+        lut[id] = hit ? make_float4(T.x, T.y, T.z, 1.0f) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
     }
-    lut[id] = make_float4(T.x, T.y, T.z, 1.0f);
 }
 
 // 256-thread workgroups covering 32x8 texels (each wave an 8x8 patch, so the
@@ -75,13 +116,13 @@ __global__ __launch_bounds__(64) void k_transmittance(const szg_atmosphere_packe
 __global__ __launch_bounds__(256) void k_skyview(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
                                                  const szg_camera_packed* __restrict__ cameras, unsigned cameraIndex,
                                                  const float4* __restrict__ tlut, int tW, int tH, float4* __restrict__ lut,
-                                                 int W, int H)
+                                                 int W, int H, int rowBegin, int rowEnd)
 {
     unsigned const tid = threadIdx.x;
     unsigned const wave = tid >> 6, lane = tid & 63u;
     int const x = (int)(blockIdx.x * 32u + wave * 8u + (lane & 7u));
-    int const y = (int)(blockIdx.y * 8u + (lane >> 3));
-    if (x >= W || y >= H)
+    int const y = rowBegin + (int)(blockIdx.y * 8u + (lane >> 3));
+    if (x >= W || y >= rowEnd)
     {
         return;
     }
@@ -137,18 +178,27 @@ __global__ __launch_bounds__(256) void k_skyview(const szg_atmosphere_packed* __
 hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, float* lut, unsigned W,
                                 unsigned H)
 {
-    unsigned const n = W * H;
-    hipLaunchKernelGGL(k_transmittance, dim3((n + 63u) / 64u), dim3(64), 0, s, d_atm, atmIndex, reinterpret_cast<float4*>(lut),
+    unsigned const n = W * H * (unsigned)T_LANES;
+    hipLaunchKernelGGL(k_transmittance, dim3((n + 255u) / 256u), dim3(256), 0, s, d_atm, atmIndex, reinterpret_cast<float4*>(lut),
                        (int)W, (int)H);
     return hipGetLastError();
 }
 
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
-                          unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H)
+                          unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
+                          unsigned rowBegin, unsigned rowEnd)
 {
-    dim3 const grid((W + 31u) / 32u, (H + 7u) / 8u);
+    if (rowEnd > H)
+    {
+        rowEnd = H;
+    }
+    if (rowBegin >= rowEnd || W == 0u)
+    {
+        return hipSuccess;
+    }
+    dim3 const grid((W + 31u) / 32u, (rowEnd - rowBegin + 7u) / 8u);
     hipLaunchKernelGGL(k_skyview, grid, dim3(256), 0, s, d_atm, atmIndex, d_cam, camIndex, reinterpret_cast<const float4*>(tlut),
-                       (int)tW, (int)tH, reinterpret_cast<float4*>(lut), (int)W, (int)H);
+                       (int)tW, (int)tH, reinterpret_cast<float4*>(lut), (int)W, (int)H, (int)rowBegin, (int)rowEnd);
     return hipGetLastError();
 }
 } // namespace szg

@@ -406,19 +406,36 @@ int szg_skyview_record_transmittance(szg_skyview_t* p, void* stream, uint32_t at
     return SZG_OK;
 }
 
+int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                        const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                                        const szg_camera_packed* d_cameras, uint32_t row_begin, uint32_t row_end)
+{
+    if (p == nullptr || d_atmospheres == nullptr || d_cameras == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_skyview_lut_rows: NULL argument");
+    }
+    if (row_begin > row_end || row_end > p->desc.skyview_height)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_skyview_lut_rows: rows [%u, %u) outside the %u-row LUT", row_begin,
+                    row_end, p->desc.skyview_height);
+    }
+    SZG_HIP(szg::launch_skyview(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, d_cameras, view_camera_index,
+                                p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
+                                p->desc.skyview_width, p->desc.skyview_height, row_begin, row_end));
+    p->haveSkyview = true;
+    return SZG_OK;
+}
+
 int szg_skyview_record_skyview_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
                                    const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
                                    const szg_camera_packed* d_cameras)
 {
-    if (p == nullptr || d_atmospheres == nullptr || d_cameras == nullptr)
+    if (p == nullptr)
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_skyview_lut: NULL argument");
     }
-    SZG_HIP(szg::launch_skyview(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, d_cameras, view_camera_index,
-                                p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
-                                p->desc.skyview_width, p->desc.skyview_height));
-    p->haveSkyview = true;
-    return SZG_OK;
+    return szg_skyview_record_skyview_lut_rows(p, stream, atmosphere_index, d_atmospheres, view_camera_index, d_cameras, 0u,
+                                               p->desc.skyview_height);
 }
 
 int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture, szg_rect draw_rect,

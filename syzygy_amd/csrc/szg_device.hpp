@@ -70,6 +70,58 @@ SZG_DEV float smoothstep(float e0, float e1, float x)
 }
 SZG_DEV float safeSqrt(float v) { return sqrtf(fmaxf(v, 0.0f)); } // atmosphere/common.glinl:23-26
 
+// ---------------------------------------------------------------------------
+// Lean exact division and square root.
+//
+// hipcc's correctly rounded `/` and sqrtf() cost ~47 and ~64 cycles per wave64 operation
+// on gfx950 (an fma costs ~2.3): every call carries the denormal/overflow scaling and the
+// special-case fix-up. The sequences below are the SAME algorithms without the scaling
+// (v_rcp_f32 / v_sqrt_f32 seed, Newton, exact fma residual corrections). They return the
+// IEEE-754 correctly rounded result — bit-identical to `/` and sqrtf() — whenever their
+// operand preconditions hold, and cost ~29 / ~39 cycles; a division whose denominator's
+// refined reciprocal is shared costs ~13. Checked on MI355X: sqrtN == sqrtf for ALL
+// binary32 inputs in its domain; divN == `/` on 4.3e9 random operand pairs with exponents
+// in [-60, 60] plus zero numerators (scratch history in DESIGN.md "lean exact ops").
+// They are used only under a wave-uniform `lean` flag that the kernels derive from the
+// atmosphere block and the ray (see leanAtmosphere / leanRay); otherwise the generic
+// operators are used, so results never depend on the flag.
+// ---------------------------------------------------------------------------
+// refined reciprocal; b finite, |b| in [2^-60, 2^60]
+SZG_DEV float rcpN(float b)
+{
+    float const y = __builtin_amdgcn_rcpf(b);
+    float const e = __builtin_fmaf(-b, y, 1.0f);
+    return __builtin_fmaf(e, y, y);
+}
+// a / b given y = rcpN(b); a == +-0 or |a| in [2^-60, 2^60]
+SZG_DEV float divR(float a, float b, float y)
+{
+    float const q0 = a * y;
+    float r = __builtin_fmaf(-b, q0, a);
+    float q = __builtin_fmaf(r, y, q0);
+    r = __builtin_fmaf(-b, q, a);
+    q = __builtin_fmaf(r, y, q);
+    return __builtin_copysignf(q, q0); // a zero quotient keeps the sign IEEE division gives it
+}
+SZG_DEV float divN(float a, float b) { return divR(a, b, rcpN(b)); }
+// sqrt(x); x == 0, x >= 2^-96 or +inf (negative / NaN -> NaN like sqrtf)
+SZG_DEV float sqrtN(float x)
+{
+    float s = __builtin_amdgcn_sqrtf(x);
+    float const sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
+    float const sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
+    float const rm = __builtin_fmaf(-sm, s, x);
+    float const rp = __builtin_fmaf(-sp, s, x);
+    s = (rm <= 0.0f) ? sm : s;
+    s = (rp > 0.0f) ? sp : s;
+    return s;
+}
+template <bool LEAN> SZG_DEV float sqrtX(float x) { return LEAN ? sqrtN(x) : sqrtf(x); }
+template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
+template <bool LEAN> SZG_DEV float divX(float a, float b) { return LEAN ? divN(a, b) : a / b; }
+template <bool LEAN> SZG_DEV float divRX(float a, float b, float y) { return LEAN ? divR(a, b, y) : a / b; }
+SZG_DEV bool inRange(float x, float lo, float hi) { return x >= lo && x <= hi; } // false for NaN
+
 // column-major 4x4 times (x, y, z, w), rows summed left to right
 struct M4
 {
@@ -186,6 +238,9 @@ struct Atm
     float sunAngularRadius;
     // hoisted sub-expressions of common.glinl:42-46
     float Ra2, Rp2, H;
+    // refined reciprocals for divR (valid when `lean`)
+    float rcpH, rcpDsR, rcpDsM, rcp15;
+    bool lean; // leanAtmosphere(): every atmosphere-level precondition of the lean ops holds
 };
 SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
 {
@@ -205,6 +260,16 @@ SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
     a.Ra2 = a.atmosphereRadius * a.atmosphereRadius;
     a.Rp2 = a.planetRadius * a.planetRadius;
     a.H = safeSqrt(a.Ra2 - a.Rp2);
+    // Preconditions of the lean ops that depend only on the atmosphere: radii, H and density scales of moderate
+    // magnitude, and the x_mu denominator rho + H - (Ra - r) bounded away from 0 for every r >= 0.9 Rp.
+    float const lo = 0x1p-30f, hi = 0x1p30f;
+    a.lean = inRange(a.planetRadius, lo, hi) && inRange(a.atmosphereRadius, lo, hi) && inRange(a.H, lo, hi) &&
+             inRange(a.densityScaleRayleigh, lo, hi) && inRange(a.densityScaleMie, lo, hi) &&
+             (a.H - a.atmosphereRadius + 0.9f * a.planetRadius >= 0x1p-20f);
+    a.rcpH = rcpN(a.lean ? a.H : 1.0f);
+    a.rcpDsR = rcpN(a.lean ? a.densityScaleRayleigh : 1.0f);
+    a.rcpDsM = rcpN(a.lean ? a.densityScaleMie : 1.0f);
+    a.rcp15 = rcpN(15.0f);
     return a;
 }
 
@@ -215,15 +280,15 @@ struct Extinction
     V3 scatteringMie;
     V3 extinction;
 };
-SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude)
+template <bool LEAN = false> SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude)
 {
-    float const densityRayleigh = szg_expf(-altitude / a.densityScaleRayleigh);
+    float const densityRayleigh = szg_expf(divRX<LEAN>(-altitude, a.densityScaleRayleigh, a.rcpDsR));
     V3 const scatteringRayleigh = a.scatteringRayleigh * densityRayleigh;
     V3 const absorptionRayleigh = a.absorptionRayleigh * densityRayleigh;
-    float const densityMie = szg_expf(-altitude / a.densityScaleMie);
+    float const densityMie = szg_expf(divRX<LEAN>(-altitude, a.densityScaleMie, a.rcpDsM));
     V3 const scatteringMie = a.scatteringMie * densityMie;
     V3 const absorptionMie = a.absorptionRayleigh * densityMie;
-    float const densityOzone = fmaxf(0.0f, 1.0f - fabsf(altitude * 1000.0f - 25.0f) / 15.0f);
+    float const densityOzone = fmaxf(0.0f, 1.0f - divRX<LEAN>(fabsf(altitude * 1000.0f - 25.0f), 15.0f, a.rcp15));
     V3 const scatteringOzone = a.scatteringOzone * densityOzone;
     V3 const absorptionOzone = a.absorptionOzone * densityOzone;
     Extinction e;
@@ -339,20 +404,22 @@ struct RadiusPart
 {
     float r, r2;        // radius, radius * radius
     float d_min, denom; // atmosphereRadius - radius, (rho + H) - d_min
+    float rcpDenom;     // rcpN(denom) when LEAN
     const float4* row0; // texel rows j0, j1 (clamped)
     const float4* row1;
     float b, omb;       // v weight and 1 - b
 };
-SZG_DEV RadiusPart radiusPart(const TLut& L, const Atm& a, float radius)
+template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const Atm& a, float radius)
 {
     RadiusPart p;
     p.r = radius;
     p.r2 = radius * radius;
-    float const rho = safeSqrt(p.r2 - a.Rp2);
+    float const rho = safeSqrtX<LEAN>(p.r2 - a.Rp2);
     p.d_min = a.atmosphereRadius - radius;
     float const d_max = rho + a.H;
     p.denom = d_max - p.d_min;
-    float const x_radius = rho / a.H;
+    p.rcpDenom = LEAN ? rcpN(p.denom) : 0.0f;
+    float const x_radius = divRX<LEAN>(rho, a.H, a.rcpH);
     float const t = L.v_bias + x_radius * L.v_scale;
     float const v = t * L.fheight - 0.5f;
     float const fv = floorf(v);
@@ -366,10 +433,10 @@ SZG_DEV RadiusPart radiusPart(const TLut& L, const Atm& a, float radius)
     p.row1 = L.texels + j1 * L.width;
     return p;
 }
-SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, const RadiusPart& p, float mu)
+template <bool LEAN = false> SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, const RadiusPart& p, float mu)
 {
-    float const d = fmaxf(-p.r * mu + safeSqrt(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f);
-    float const x_mu = (d - p.d_min) / p.denom;
+    float const d = fmaxf(-p.r * mu + safeSqrtX<LEAN>(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f);
+    float const x_mu = divRX<LEAN>(d - p.d_min, p.denom, p.rcpDenom);
     float const s = L.u_bias + x_mu * L.u_scale;
     float const u = s * L.fwidth - 0.5f;
     float const fu = floorf(u);
@@ -397,8 +464,8 @@ SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, const RadiusPart& p, float mu
 // common.glinl:40-66 + :138-143 : sample at (radius, mu)
 SZG_DEV V3 sampleT_RadiusMu(const TLut& L, const Atm& a, float radius, float mu)
 {
-    RadiusPart const p = radiusPart(L, a, radius);
-    return sampleT_at(L, a, p, mu);
+    RadiusPart const p = radiusPart<false>(L, a, radius);
+    return sampleT_at<false>(L, a, p, mu);
 }
 
 // common.glinl:104-112
@@ -412,14 +479,15 @@ SZG_DEV V3 sampleT_Ray(const TLut& L, const Atm& a, V3 position, V3 direction)
 // common.glinl:114-136. The flipped branch samples with -direction, whose mu is the exact
 // negation of the unflipped one (negation commutes with every rounding), so one code path
 // with a sign select reproduces both branches.
+template <bool LEAN = false>
 SZG_DEV V3 segmentRatio(const TLut& L, const Atm& a, const RadiusPart& pFrom, float fromDotDir, float lenFrom,
                         const RadiusPart& pTo, float toDotDir, float lenTo, float lenDir)
 {
     bool const flip = fromDotDir < 0.0f;
-    float const muFrom = fromDotDir / (lenFrom * lenDir);
-    float const muTo = toDotDir / (lenTo * lenDir);
-    V3 const Tf = sampleT_at(L, a, pFrom, flip ? -muFrom : muFrom);
-    V3 const Tt = sampleT_at(L, a, pTo, flip ? -muTo : muTo);
+    float const muFrom = divX<LEAN>(fromDotDir, lenFrom * lenDir);
+    float const muTo = divX<LEAN>(toDotDir, lenTo * lenDir);
+    V3 const Tf = sampleT_at<LEAN>(L, a, pFrom, flip ? -muFrom : muFrom);
+    V3 const Tt = sampleT_at<LEAN>(L, a, pTo, flip ? -muTo : muTo);
     V3 const q = flip ? (Tt / Tf) : (Tf / Tt);
     return clamp01(q);
 }
@@ -428,9 +496,9 @@ SZG_DEV V3 sampleT_Segment(const TLut& L, const Atm& a, V3 from, V3 to)
     V3 const direction = normalize(to - from);
     float const lenFrom = length(from);
     float const lenTo = length(to);
-    RadiusPart const pf = radiusPart(L, a, lenFrom);
-    RadiusPart const pt = radiusPart(L, a, lenTo);
-    return segmentRatio(L, a, pf, dot(from, direction), lenFrom, pt, dot(to, direction), lenTo, length(direction));
+    RadiusPart const pf = radiusPart<false>(L, a, lenFrom);
+    RadiusPart const pt = radiusPart<false>(L, a, lenTo);
+    return segmentRatio<false>(L, a, pf, dot(from, direction), lenFrom, pt, dot(to, direction), lenTo, length(direction));
 }
 
 // common.glinl:263-279
@@ -453,73 +521,65 @@ SZG_DEV float phaseMie(float cosine, float g)
 //   LUT tap and mu_sunAndStepDirection of sampleTransmittanceLUT_RayMarchStep /
 //   stepRadiusMu (325, 349/357). stepRadiusMu(originStep, t) is evaluated once
 //   per step and used for both sampleStep (389) and `end` (343).
-SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 direction, float sampleDistance)
+struct MarchSetup
 {
-    V3 const scatteringDir = -normalize(direction);
-    float const radius = length(origin);
-    float const mu = dot(origin, direction) / (length(origin) * length(direction));
-    V3 const toSun = -a.incidentDirectionSun;
-    float const mu_sun = dot(origin, toSun) / (length(origin) * length(a.incidentDirectionSun));
+    V3 origin, scatteringDir;
+    float dS, pR, pM, sin_sunRadius, cos_sunRadius;
+    float mu_sunAndStep, r_mu, two_r_mu, r2, r_musun;
+    bool up;
+    V3 T_origin;
+};
 
-    float const incidentCosine = dot(a.incidentDirectionSun, scatteringDir);
-    float const pR = phaseRayleigh(incidentCosine);
-    float const pM = phaseMie(incidentCosine, 0.8f);
-    float const sin_sunRadius = szg_sinf(a.sunAngularRadius);
-    float const cos_sunRadius = szg_cosf(a.sunAngularRadius);
-
-    // stepRadiusMu invariants (common.glinl:325)
-    float const mu_sunAndStep = safeSqrt(mu_sun * mu - safeSqrt((1.0f - mu_sun * mu_sun) * (1.0f - mu * mu)));
-    float const r_mu = radius * mu;
-    float const two_r_mu = 2.0f * radius * mu;
-    float const r2 = radius * radius;
-    float const r_musun = radius * mu_sun;
-    bool const up = mu > 0.0f;
-    V3 const T_origin = sampleT_RadiusMu(L, a, radius, up ? mu : -mu);
-
+template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const MarchSetup& m)
+{
     V3 luminance = splat(0.0f);
-    float const dS = sampleDistance / 32.0f;
     // `end` of step i and `begin` of step i+1 are the same expression (common.glinl:386-387),
     // so its length and radius part are carried from one iteration to the next.
-    V3 begin = origin - (0.0f * dS) * scatteringDir;
-    float lenBegin = length(begin);
-    RadiusPart pBegin = radiusPart(L, a, lenBegin);
+    V3 begin = m.origin - (0.0f * m.dS) * m.scatteringDir;
+    float lenBegin = sqrtX<LEAN>(dot(begin, begin));
+    RadiusPart pBegin = radiusPart<LEAN>(L, a, lenBegin);
 #pragma unroll 1
     for (unsigned i = 0; i < 32u; i++)
     {
         float const fi = (float)i;
-        float const t = fi * dS;
-        V3 const end = origin - ((float)(i + 1u) * dS) * scatteringDir;
-        float const lenEnd = length(end);
-        RadiusPart const pEnd = radiusPart(L, a, lenEnd);
+        float const t = fi * m.dS;
+        V3 const end = m.origin - ((float)(i + 1u) * m.dS) * m.scatteringDir;
+        float const lenEnd = sqrtX<LEAN>(dot(end, end));
+        RadiusPart const pEnd = radiusPart<LEAN>(L, a, lenEnd);
 
         // stepRadiusMu(originStep, t), common.glinl:329-331
-        float const s_radius = safeSqrt(t * t + two_r_mu * t + r2);
-        float const s_mu = (r_mu + t) / s_radius;
-        float const s_musun = (r_musun + t * mu_sunAndStep) / s_radius;
-        RadiusPart const pStep = radiusPart(L, a, s_radius);
+        float const s_radius = safeSqrtX<LEAN>(t * t + m.two_r_mu * t + m.r2);
+        float const yS = LEAN ? rcpN(s_radius) : 0.0f;
+        float const s_mu = divRX<LEAN>(m.r_mu + t, s_radius, yS);
+        float const s_musun = divRX<LEAN>(m.r_musun + t * m.mu_sunAndStep, s_radius, yS);
+        RadiusPart const pStep = radiusPart<LEAN>(L, a, s_radius);
 
         float const altitude = lenBegin - a.planetRadius;
 
         // sampleTransmittanceLUT_Sun, common.glinl:145-172
-        float const sin_hz = a.planetRadius / s_radius;
-        float const cos_hz = -safeSqrt(1.0f - sin_hz * sin_hz);
-        V3 const T_atm = sampleT_at(L, a, pStep, s_musun);
-        float const angularFactor = smoothstep(-sin_hz * sin_sunRadius, sin_hz * sin_sunRadius, s_musun - cos_hz * cos_sunRadius);
+        float const sin_hz = divRX<LEAN>(a.planetRadius, s_radius, yS);
+        float const cos_hz = -safeSqrtX<LEAN>(1.0f - sin_hz * sin_hz);
+        V3 const T_atm = sampleT_at<LEAN>(L, a, pStep, s_musun);
+        float const e0 = -sin_hz * m.sin_sunRadius;
+        float const e1 = sin_hz * m.sin_sunRadius;
+        float const ss = clampf(divX<LEAN>((s_musun - cos_hz * m.cos_sunRadius) - e0, e1 - e0), 0.0f, 1.0f);
+        float const angularFactor = ss * ss * (3.0f - 2.0f * ss);
         V3 const T_sun = T_atm * angularFactor;
 
-        Extinction const ex = sampleExtinction(a, altitude);
+        Extinction const ex = sampleExtinction<LEAN>(a, altitude);
 
         // sampleTransmittanceLUT_RayMarchStep, common.glinl:336-361
-        V3 const T_end = sampleT_at(L, a, pStep, up ? s_mu : -s_mu);
-        V3 const ratio = clamp01(up ? (T_origin / T_end) : (T_end / T_origin));
+        V3 const T_end = sampleT_at<LEAN>(L, a, pStep, m.up ? s_mu : -s_mu);
+        V3 const ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
         V3 const T_begin = (t < 0.0000001f) ? splat(1.0f) : ratio;
 
-        V3 const phaseTimesScattering = ex.scatteringRayleigh * pR + ex.scatteringMie * pM;
+        V3 const phaseTimesScattering = ex.scatteringRayleigh * m.pR + ex.scatteringMie * m.pM;
 
-        // sampleTransmittanceLUT_Segment(begin, end), common.glinl:114-136
+        // sampleTransmittanceLUT_Segment(begin, end), common.glinl:114-136. The segment can be arbitrarily
+        // short (geometry close to the camera), so its normalisation keeps the generic operators.
         V3 const segDir = normalize(end - begin);
-        V3 const T_path =
-            segmentRatio(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd, length(segDir));
+        V3 const T_path = segmentRatio<LEAN>(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd,
+                                             sqrtX<LEAN>(dot(segDir, segDir)));
         V3 const integral = (splat(1.0f) - T_path) / ex.extinction;
         luminance = luminance + phaseTimesScattering * T_sun * integral * T_begin;
 
@@ -528,6 +588,49 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
         pBegin = pEnd;
     }
     return luminance;
+}
+
+SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 direction, float sampleDistance)
+{
+    MarchSetup m;
+    m.origin = origin;
+    m.scatteringDir = -normalize(direction);
+    float const radius = length(origin);
+    float const mu = dot(origin, direction) / (length(origin) * length(direction));
+    V3 const toSun = -a.incidentDirectionSun;
+    float const mu_sun = dot(origin, toSun) / (length(origin) * length(a.incidentDirectionSun));
+
+    float const incidentCosine = dot(a.incidentDirectionSun, m.scatteringDir);
+    m.pR = phaseRayleigh(incidentCosine);
+    m.pM = phaseMie(incidentCosine, 0.8f);
+    m.sin_sunRadius = szg_sinf(a.sunAngularRadius);
+    m.cos_sunRadius = szg_cosf(a.sunAngularRadius);
+
+    // stepRadiusMu invariants (common.glinl:325)
+    m.mu_sunAndStep = safeSqrt(mu_sun * mu - safeSqrt((1.0f - mu_sun * mu_sun) * (1.0f - mu * mu)));
+    m.r_mu = radius * mu;
+    m.two_r_mu = 2.0f * radius * mu;
+    m.r2 = radius * radius;
+    m.r_musun = radius * mu_sun;
+    m.up = mu > 0.0f;
+    m.T_origin = sampleT_RadiusMu(L, a, radius, m.up ? mu : -mu);
+    m.dS = sampleDistance / 32.0f;
+
+    // leanRay: every radius met along the path stays >= 0.9 Rp and of moderate magnitude, the path length is
+    // moderate, and the smoothstep span 2 * sin_hz * sin(sunRadius) is a normal number. The closest approach of
+    // the segment [0, L] to the planet centre is at t* = -r*mu when that lies inside the segment.
+    float const L2 = sampleDistance * sampleDistance + m.two_r_mu * sampleDistance + m.r2;
+    float const tStar = -m.r_mu;
+    float const rmin2 = (tStar > 0.0f && tStar < sampleDistance) ? m.r2 * (1.0f - mu * mu) : fminf(m.r2, L2);
+    float const floor2 = (0.9f * a.planetRadius) * (0.9f * a.planetRadius);
+    bool const lean = a.lean && rmin2 >= floor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(sampleDistance, 0.0f, 0x1p30f) &&
+                      m.sin_sunRadius >= 0x1p-30f;
+    // wave-uniform choice: one lane outside the domain sends its whole wave down the generic path
+    if (__all(lean))
+    {
+        return marchLoop<true>(L, a, m);
+    }
+    return marchLoop<false>(L, a, m);
 }
 
 // ---------------------------------------------------------------------------
@@ -542,6 +645,10 @@ struct Material
     float occlusion;
     float specularPower;
     float metallic;
+    // per-pixel invariants of the BRDF: diffuseBRDF() = subscattering / pi (pbrFunctions.glinl:38) and the
+    // Blinn-Phong normalisation (specularPower + 2) / 8 (pbrFunctions.glinl:49)
+    V3 diffuse;
+    float normalization;
 };
 
 // pbrFunctions.glinl:3-20
@@ -558,21 +665,24 @@ SZG_DEV Material convertPBR(V4 position, V4 normal, V4 diffuse, V4 specular, V4 
     m.reflectance = mix(splat(0.04f), metallicReflectance, splat(m.metallic));
     m.occlusion = orm.x;
     m.specularPower = szg_powf(160.0f, 1.0f - orm.y);
+    m.diffuse = m.subscattering / 3.14159265359f;
+    m.normalization = (m.specularPower + 2.0f) / 8.0f;
     return m;
 }
 
 // computeLightContribution's BRDF part (lights.comp:93-108 / camera.comp:258-271):
-// mix(diffuseBRDF, specularBRDF, fresnel) for outgoing light/view directions.
-SZG_DEV V3 brdfMix(const Material& m, V3 lightDir, V3 viewDir)
+// mix(diffuseBRDF, specularBRDF, fresnel) for outgoing light/view directions. LEAN: the caller has checked
+// that |lightDir + viewDir|^2 >= 2^-40 (normalisation with the lean exact ops).
+template <bool LEAN = false> SZG_DEV V3 brdfMix(const Material& m, V3 lightDir, V3 viewDir)
 {
-    V3 const diffuse = m.subscattering / 3.14159265359f;
-    V3 const h = normalize(lightDir + viewDir);
+    V3 const hs = lightDir + viewDir;
+    float const hd = dot(hs, hs);
+    V3 const h = hs * divX<LEAN>(1.0f, sqrtX<LEAN>(hd));
     float const microfacet = szg_powf(clampf(dot(h, m.normal), 0.0f, 1.0f), m.specularPower);
-    float const normalization = (m.specularPower + 2.0f) / 8.0f;
-    V3 const specular = splat(normalization * microfacet);
+    V3 const specular = splat(m.normalization * microfacet);
     float const p = szg_powf(1.0f - clampf(dot(h, lightDir), 0.0f, 1.0f), 5.0f);
     V3 const fresnel = m.reflectance + (splat(1.0f) - m.reflectance) * p;
-    return mix(diffuse, specular, fresnel);
+    return mix(m.diffuse, specular, fresnel);
 }
 
 // pbrFunctions.glinl:22-32

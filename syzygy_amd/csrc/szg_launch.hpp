@@ -12,7 +12,7 @@ namespace szg
 // through scalar (wave-uniform) loads. 36 dwords.
 struct LightRec
 {
-    float shadowMatrix[16]; // TO_TEX_COORD_MAT * projection * view (shadowmap.glinl:19)
+    float shadowRows[16];   // TO_TEX_COORD_MAT * projection * view (shadowmap.glinl:19), ROW-major: rows[r*4+c]
     float dir[3];           // normalize(-forward) (lights.comp:67/78)
     float falloffFactor;
     float colorStrength[3]; // color.rgb * strength (lights.comp:68/88)
@@ -22,7 +22,8 @@ struct LightRec
     const float* map; // D32F shadow map or nullptr
     unsigned mapWidth, mapHeight;
     unsigned mapPitchFloats;
-    unsigned pad[3];
+    unsigned leanOK; // falloffDistance / falloffFactor / colour*strength of moderate magnitude (lean exact ops allowed)
+    unsigned pad[2];
 };
 static_assert(sizeof(LightRec) == 144, "LightRec layout");
 
@@ -42,7 +43,8 @@ struct TileArgs
 hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, float* lut, unsigned W,
                                 unsigned H);
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
-                          unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H);
+                          unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
+                          unsigned rowBegin, unsigned rowEnd);
 hipError_t launch_light_prep(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount, unsigned dirSkip,
                              const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_slots,
                              unsigned slotCount, LightRec* d_out);

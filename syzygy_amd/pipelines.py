@@ -235,6 +235,16 @@ class DeferredShadingPipeline:
         return out
 
 
+class _RawDeviceArray:
+    def __init__(self, ptr, shape):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": "<f4", "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+
+
+def _alias_tensor(ptr, shape):
+    return torch.as_tensor(_RawDeviceArray(ptr, shape), device="cuda")
+
+
 def _hip_memcpy2d(dst_ptr, dpitch, src_ptr, spitch, width_bytes, height):
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy2D.restype = C.c_int
@@ -291,6 +301,18 @@ class SkyViewComputePipeline:
         check(lib().szg_skyview_record_skyview_lut(self._h, _stream_handle(cmd), int(atmosphereIndex),
                                                    C.c_void_p(atmospheres.deviceAddress()), int(viewCameraIndex),
                                                    C.c_void_p(cameras.deviceAddress())))
+
+    def recordSkyViewLUTRows(self, cmd, atmosphereIndex, atmospheres, viewCameraIndex, cameras, rowBegin, rowEnd):
+        """Multi-GPU extension: texel rows [rowBegin, rowEnd) only (see rowtile.allgather_skyview_lut)."""
+        check(lib().szg_skyview_record_skyview_lut_rows(self._h, _stream_handle(cmd), int(atmosphereIndex),
+                                                        C.c_void_p(atmospheres.deviceAddress()), int(viewCameraIndex),
+                                                        C.c_void_p(cameras.deviceAddress()), int(rowBegin), int(rowEnd)))
+
+    def skyviewLUT_tensor(self):
+        """The sky-view LUT memory the C library owns, aliased (zero copy) as a torch float32 tensor
+        [height, width, 4] through __cuda_array_interface__."""
+        im = self.skyviewLUT()
+        return _alias_tensor(im.data, (im.height, im.width, 4))
 
     def recordComposite(self, cmd, sceneTexture, drawRect, gbuffer, shadowMaps, atmosphereIndex, atmospheres, viewCameraIndex,
                         cameras, sunLightIndex, lights, tile=None):

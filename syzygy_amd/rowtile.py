@@ -78,3 +78,21 @@ def compose(gathered, height, nranks, block_rows=DEFAULT_BLOCK_ROWS, out=None, s
     check(lib().szg_compose_rowtiles(C.c_void_p(handle), C.c_void_p(gathered.data_ptr()), srows * width * 8, nranks, block_rows,
                                      C.byref(im), width, height))
     return out
+
+
+def lut_rows(height, rank, nranks):
+    """[begin, end) rows of a LUT of `height` rows that `rank` computes (contiguous, equal: the all-gather
+    needs equal slices, so height must divide by nranks)."""
+    if height % max(nranks, 1) != 0:
+        raise ValueError(f"LUT height {height} is not divisible by {nranks} ranks")
+    n = height // max(nranks, 1)
+    return rank * n, (rank + 1) * n
+
+
+def allgather_lut(lut, rank, nranks, group=None):
+    """Second (optional) collective: every rank has filled rows lut_rows(...) of `lut` ([H, W, 4] float32,
+    the same buffer on every rank); exchange the slices in place so that every rank holds the whole LUT."""
+    if nranks <= 1:
+        return
+    b, e = lut_rows(lut.shape[0], rank, nranks)
+    dist.all_gather_into_tensor(lut.view(-1), lut[b:e].reshape(-1).clone(), group=group)

@@ -101,6 +101,33 @@ def test_skyview_lut_reference_size_band(gpu):
     sky.destroy()
 
 
+def test_skyview_lut_row_slices_equal_the_full_lut(gpu):
+    """Multi-GPU extension: N row slices (szg_skyview_record_skyview_lut_rows) == the whole LUT, bit for bit;
+    the LUT memory aliased as a torch tensor is the same storage."""
+    inp = util.Inputs(64, 64, elevation_degrees=20.0)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(256, 64), skyview_extent=(256, 128))
+    sky.recordTransmittance(None, 0, atmospheres)
+    sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    torch.cuda.synchronize()
+    full = sky.download_lut(sky.skyviewLUT())
+    alias = sky.skyviewLUT_tensor()
+    assert alias.shape == (128, 256, 4) and (alias.cpu().numpy().view(np.uint32) == full.view(np.uint32)).all()
+    alias.zero_()
+    from syzygy_amd import rowtile
+
+    for rank in (2, 0, 3, 1):
+        b, e = rowtile.lut_rows(128, rank, 4)
+        sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, b, e)
+    torch.cuda.synchronize()
+    assert (sky.download_lut(sky.skyviewLUT()).view(np.uint32) == full.view(np.uint32)).all()
+    from syzygy_amd import SzgError
+
+    with pytest.raises(SzgError):
+        sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, 100, 200)
+    sky.destroy()
+
+
 # ---------------------------------------------------------------------------
 # G-buffer fill: arithmetic only -> bit-exact
 # ---------------------------------------------------------------------------

@@ -75,6 +75,45 @@ def test_rowtile_gather_compose_gloo(world, block_rows, size):
     assert ok == 1 and nonzero == 1
 
 
+def _lut_worker(rank, world, port, out_path):
+    import torch.distributed as dist
+
+    from syzygy_amd import rowtile
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        H, W = 16, 8
+        want = torch.arange(H * W * 4, dtype=torch.float32).reshape(H, W, 4)
+        lut = torch.full((H, W, 4), -1.0)
+        b, e = rowtile.lut_rows(H, rank, world)
+        lut[b:e] = want[b:e]  # this rank's slice
+        rowtile.allgather_lut(lut, rank, world)
+        np.save(out_path + f".{rank}.npy", np.array([int(torch.equal(lut, want))]))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_lut_slices_allgather_gloo(world):
+    with tempfile.TemporaryDirectory() as tmp:
+        out_path = os.path.join(tmp, "r")
+        mp.spawn(_lut_worker, args=(world, _free_port(), out_path), nprocs=world, join=True)
+        for r in range(world):
+            assert np.load(out_path + f".{r}.npy")[0] == 1
+
+
+def test_lut_rows_partition():
+    from syzygy_amd import rowtile
+
+    assert [rowtile.lut_rows(1024, r, 8) for r in range(8)] == [(r * 128, (r + 1) * 128) for r in range(8)]
+    assert rowtile.lut_rows(1024, 0, 1) == (0, 1024)
+    with pytest.raises(ValueError):
+        rowtile.lut_rows(1024, 0, 3)
+
+
 def test_global_rows_cover_the_frame_once():
     from syzygy_amd import rowtile
 
