@@ -58,7 +58,7 @@ def main():
     ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
     ap.add_argument("--elevation", type=float, default=35.0, help="sun elevation in degrees")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the frame the CPU baseline shades")
+    ap.add_argument("--cpu-rows", type=int, default=540, help="rows of the frame the CPU baseline shades")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -243,7 +243,7 @@ def cpu_baseline(args, wl, atm, cam, sun, moon, spots, syn):
     from syzygy_amd import abi, lib
 
     W, H, SPOTS = wl["width"], wl["height"], wl["spots"]
-    threads = max(1, min(os.cpu_count() or 1, 64))
+    threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 64))
     sample_rows = min(args.cpu_rows, H)
     nranks = H // sample_rows
     tile = abi.RowTile(1, nranks // 2, nranks, lib().szg_rowtile_local_rows(H, 1, nranks // 2, nranks))

@@ -280,14 +280,14 @@ typedef struct szg_skyview_desc
     uint32_t transmittance_height; /* reference: 128 */
     uint32_t skyview_width;        /* reference: 2048 (skyview.cpp:175) */
     uint32_t skyview_height;       /* reference: 1024 */
-    uint32_t flags;                /* SZG_SKYVIEW_* */
+    uint32_t flags;                /* must be 0 */
     uint32_t padding;
 } szg_skyview_desc;
 
-/* Reuse LUTs of the previous record when atmosphere block / camera position are
- * byte-identical (results identical; the reference recomputes every frame,
- * skyview.cpp:799-893). Off by default. */
-#define SZG_SKYVIEW_CACHE_LUTS 1u
+/* No flags are defined yet. To reuse the LUTs across frames whose atmosphere block, sun direction and camera
+ * position are unchanged (the reference recomputes them every frame, skyview.cpp:799-893; results are
+ * identical either way), call szg_skyview_record_composite() alone instead of
+ * szg_skyview_record_draw_commands(). */
 
 /* skyview.hpp:36-37 `create(device, allocator)`; returns SZG_OK and *out, or a
  * negative status and *out = NULL (reference: nullptr, skyview.cpp:713-740). */

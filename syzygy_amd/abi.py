@@ -25,8 +25,6 @@ TEXEL_BYTES = {
     SZG_FORMAT_D32_SFLOAT: 4,
 }
 
-SZG_SKYVIEW_CACHE_LUTS = 1
-
 
 class Mat4(C.Structure):
     _fields_ = [("m", C.c_float * 16)]

@@ -111,7 +111,7 @@ struct GBufferPtrsC
     szg_image diffuse, specular, normal, position, orm;
 };
 
-__global__ __launch_bounds__(256) void k_composite(szg_image color, szg_image depth, szg_image debug, GBufferPtrsC g,
+__global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image depth, szg_image debug, GBufferPtrsC g,
                                                    unsigned drawW, unsigned drawH, unsigned localRows, RowMap rm,
                                                    ShadowSlot sunSlot, const szg_atmosphere_packed* __restrict__ atmospheres,
                                                    unsigned atmosphereIndex, const szg_camera_packed* __restrict__ cameras,
@@ -273,6 +273,19 @@ __global__ __launch_bounds__(256) void k_composite(szg_image color, szg_image de
     }
 
     // ---- phase B ---------------------------------------------------------
+    // The march needs ~125 VGPRs by itself; what phase C wants back (12 floats) is parked in LDS meanwhile so
+    // that the kernel fits 168 VGPRs = 3 waves per SIMD instead of 2 (LDS is otherwise unused here; [k][tid]
+    // indexing is conflict-free).
+    __shared__ float s_park[12][256];
+    {
+        float const park[12] = {base.x, base.y, base.z, coef.x, coef.y, coef.z, env2.x, env2.y, env2.z,
+                                surfaceLuminance.x, surfaceLuminance.y, surfaceLuminance.z};
+#pragma unroll
+        for (int k = 0; k < 12; k++)
+        {
+            s_park[k][tid] = park[k];
+        }
+    }
     V3 ap0 = splat(0.0f), ap1 = splat(0.0f);
 #pragma unroll 1
     for (int k = 0; k < 2; k++)
@@ -295,6 +308,10 @@ __global__ __launch_bounds__(256) void k_composite(szg_image color, szg_image de
         }
     }
 
+    base = mk3(s_park[0][tid], s_park[1][tid], s_park[2][tid]);
+    coef = mk3(s_park[3][tid], s_park[4][tid], s_park[5][tid]);
+    env2 = mk3(s_park[6][tid], s_park[7][tid], s_park[8][tid]);
+    surfaceLuminance = mk3(s_park[9][tid], s_park[10][tid], s_park[11][tid]);
     // ---- phase C ---------------------------------------------------------
     // sky:      transfer = env(position, direction)
     // geometry: transfer = (surfaceTransfer + AP) + coef * env(reflection)

@@ -247,7 +247,6 @@ struct szg_skyview
     szg_skyview_desc desc{};
     float* d_transmittance = nullptr;
     float* d_skyview = nullptr;
-    // LUT cache keys (SZG_SKYVIEW_CACHE_LUTS)
     bool haveTransmittance = false, haveSkyview = false;
 };
 
@@ -327,6 +326,10 @@ int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int de
         d.skyview_height > 16384u)
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_create: LUT extents out of range");
+    }
+    if (d.flags != 0u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_create: unknown flags 0x%x", d.flags);
     }
     int const rc = select_device(device);
     if (rc != SZG_OK)

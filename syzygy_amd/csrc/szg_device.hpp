@@ -400,13 +400,17 @@ SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float f
 // part that depends only on the radius (v coordinate, row pair and row weights) and the
 // part that depends on mu. Two taps at the same radius share the first part; every
 // operation and its order are those of the unsplit evaluation.
+struct Rgb
+{
+    float x, y, z;
+};
 struct RadiusPart
 {
     float r, r2;        // radius, radius * radius
     float d_min, denom; // atmosphereRadius - radius, (rho + H) - d_min
     float rcpDenom;     // rcpN(denom) when LEAN
-    const float4* row0; // texel rows j0, j1 (clamped)
-    const float4* row1;
+    unsigned row0;      // texel index of the start of rows j0, j1 (clamped); 32-bit so that the taps use
+    unsigned row1;      // SGPR-base + VGPR-offset addressing instead of 64-bit VALU address arithmetic
     float b, omb;       // v weight and 1 - b
 };
 template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const Atm& a, float radius)
@@ -429,8 +433,8 @@ template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const 
     int j1 = j0 + 1;
     j0 = min(max(j0, 0), L.height - 1);
     j1 = min(max(j1, 0), L.height - 1);
-    p.row0 = L.texels + j0 * L.width;
-    p.row1 = L.texels + j1 * L.width;
+    p.row0 = (unsigned)(j0 * L.width);
+    p.row1 = (unsigned)(j1 * L.width);
     return p;
 }
 template <bool LEAN = false> SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, const RadiusPart& p, float mu)
@@ -445,10 +449,12 @@ template <bool LEAN = false> SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, 
     int i1 = i0 + 1;
     i0 = min(max(i0, 0), L.width - 1);
     i1 = min(max(i1, 0), L.width - 1);
-    float4 const t00 = p.row0[i0];
-    float4 const t10 = p.row0[i1];
-    float4 const t01 = p.row1[i0];
-    float4 const t11 = p.row1[i1];
+    // only .rgb is consumed (common.glinl:111, :142): 12-byte loads keep 16 VGPRs per step out of flight
+    const char* const base = reinterpret_cast<const char*>(L.texels);
+    Rgb const t00 = *reinterpret_cast<const Rgb*>(base + ((p.row0 + (unsigned)i0) << 4));
+    Rgb const t10 = *reinterpret_cast<const Rgb*>(base + ((p.row0 + (unsigned)i1) << 4));
+    Rgb const t01 = *reinterpret_cast<const Rgb*>(base + ((p.row1 + (unsigned)i0) << 4));
+    Rgb const t11 = *reinterpret_cast<const Rgb*>(base + ((p.row1 + (unsigned)i1) << 4));
     float const oma = 1.0f - al;
     float const w00 = oma * p.omb;
     float const w10 = al * p.omb;

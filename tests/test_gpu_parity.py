@@ -371,6 +371,47 @@ def test_full_frame_chain_matches_oracle(gpu, elevation):
 
 
 # ---------------------------------------------------------------------------
+# inputs outside the domain of the lean exact ops: the kernels must take their generic code path
+# (szg_device.hpp leanAtmosphere / leanRay) and still match the oracle
+# ---------------------------------------------------------------------------
+def _thin_shell(a):
+    a.atmosphereRadiusMegameters = a.planetRadiusMegameters * (1.0 + 1e-4)  # H - Ra + 0.9 Rp < 0
+
+
+def _tiny_density_scale(a):
+    a.altitudeDecayMieMegameters = 2.0 ** -34  # outside [2^-30, 2^30]
+
+
+@pytest.mark.parametrize("edit", [_thin_shell, _tiny_density_scale])
+def test_generic_path_unusual_atmospheres(gpu, edit):
+    inp = util.Inputs(128, 72, elevation_degrees=30.0, spots=6, atmosphere_edit=edit)
+    got, got_q = render_gpu(gpu, inp, lut=((128, 32), (128, 64)))
+    frame = render_oracle(gpu, inp, lut=((128, 32), (128, 64)))
+    assert_close(got, frame.debug, what=f"full frame, {edit.__name__}")
+    assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+
+
+def test_generic_path_camera_far_below_ground(gpu):
+    """Unphysical on purpose (the reference has a TODO for it, common.glinl:294): rays whose radius drops under
+    0.9 R_planet fail leanRay and use the generic operators; results still equal the oracle's, NaNs included."""
+    from syzygy_amd import scene
+
+    cam = scene.default_camera()
+    cam.cameraPosition[:] = [0.0, 1.2e6, -13.0]  # +y is down: 1200 km below the surface
+    inp = util.Inputs(96, 54, elevation_degrees=30.0, spots=2, camera=cam)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(128, 32), skyview_extent=(128, 64))
+    tlut = gpu.ob.transmittance_lut(inp.atm, 128, 32, threads=8)
+    sky.upload_lut(sky.transmittanceLUT(), tlut)
+    sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    torch.cuda.synchronize()
+    got = sky.download_lut(sky.skyviewLUT())
+    want = gpu.ob.skyview_lut(inp.atm, inp.cam, tlut, 128, 64, threads=8)
+    assert_close(got[..., :3], want[..., :3], atol=1e-9, what="sky-view LUT, camera below ground")
+    sky.destroy()
+
+
+# ---------------------------------------------------------------------------
 # row tiling (multi-GPU partition): every rank's tile equals its rows of the whole frame
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("nranks,block_rows", [(2, 8), (3, 4), (8, 16)])

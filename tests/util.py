@@ -39,10 +39,12 @@ def assert_close(a, b, rtol=RTOL, atol=ATOL_COLOR, what=""):
 class Inputs:
     """Packed parameter blocks for one frame."""
 
-    def __init__(self, width, height, elevation_degrees=70.0, spots=64, camera=None, grid=(6, 4)):
+    def __init__(self, width, height, elevation_degrees=70.0, spots=64, camera=None, grid=(6, 4), atmosphere_edit=None):
         self.width, self.height = width, height
         self.synthetic = scene.SyntheticScene(grid=grid)
         self.atmosphere = scene.default_atmosphere(scene.sun_euler_for_elevation(elevation_degrees))
+        if atmosphere_edit is not None:
+            atmosphere_edit(self.atmosphere)
         self.atm, self.sun, self.moon = scene.atmosphere_baked(self.atmosphere, self.synthetic.bounds)
         self.camera = camera if camera is not None else scene.default_camera()
         self.cam = scene.camera_packed(self.camera, width / height)
