@@ -327,6 +327,33 @@ int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene
                                  const szg_camera_packed* d_cameras, uint32_t sun_light_index,
                                  const szg_directional_light_packed* d_lights);
 
+/* ---- Aerial-perspective froxel LUT + fast composite (north_star item) ------------------------
+ * NO reference counterpart: the reference marches the aerial perspective inline per geometry pixel
+ * (camera.comp:273-275). This opt-in extension precomputes it on a SZG_AERIAL_W x _H x _D froxel grid over the
+ * view frustum. The TEXEL VALUES are pinned by the reference's math: froxel (i, j, k) holds
+ *   luminance     = computeLuminanceScatteringIntegral(position, direction(i, j), d_k)   (common.glinl:364-424)
+ *   transmittance = sampleTransmittanceLUT_Segment(position, position + d_k * direction)  (common.glinl:114-136)
+ * with direction(i, j) the camera.comp:324-328 view ray through the froxel centre ((i + .5) / W, (j + .5) / H) and
+ * d_k = (k + .5) / D * max_distance_mm; they are parity-checked against the oracle. Only their trilinear USE by
+ * szg_skyview_record_composite_fast() is approximate, so that mode is never part of the parity frame. */
+#define SZG_AERIAL_W 32u
+#define SZG_AERIAL_H 32u
+#define SZG_AERIAL_D 32u
+int szg_skyview_record_aerial_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                  const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                                  const szg_camera_packed* d_cameras, float max_distance_mm);
+/* The two volumes as images of SZG_AERIAL_W x (SZG_AERIAL_H * SZG_AERIAL_D) RGBA32F texels (slice k = rows
+ * [k * H, (k + 1) * H)). */
+int szg_skyview_aerial_lut(const szg_skyview_t* p, szg_image* out_luminance, szg_image* out_transmittance);
+/* szg_skyview_record_composite() with the geometry pixels' inline 32-step march replaced by one trilinear fetch
+ * of the aerial LUT recorded last (APPROXIMATE; sky pixels and every other term are unchanged). */
+int szg_skyview_record_composite_fast(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture,
+                                      szg_rect draw_rect, const szg_rowtile* tile, const szg_gbuffer* gbuffer,
+                                      const szg_shadowmaps* shadow_maps, uint32_t atmosphere_index,
+                                      const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                                      const szg_camera_packed* d_cameras, uint32_t sun_light_index,
+                                      const szg_directional_light_packed* d_lights);
+
 /* Accessors to the LUT images the pipeline owns (skyview.hpp:52-97 `map`). */
 int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out);
 int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out);
@@ -394,6 +421,19 @@ int szg_deferred_set_shadow_map(szg_deferred_t* p, uint32_t index, const szg_ima
 /* deferred.hpp:114-115 */
 int szg_deferred_get_configuration(const szg_deferred_t* p, szg_deferred_configuration* out);
 int szg_deferred_set_configuration(szg_deferred_t* p, const szg_deferred_configuration* cfg);
+
+/* ------------------------------------------------------------------------- */
+/* OETF: the pass right after the path                      */
+/* ------------------------------------------------------------------------- */
+/* editor/editorconfig.hpp:5-10 GammaTransferFunction */
+#define SZG_OETF_PURE_GAMMA 0u /* shaders/transfer/oetf_pure_gamma.comp:9  pow(x, 1/2.2) */
+#define SZG_OETF_SRGB 1u       /* shaders/transfer/oetf_srgb.comp:9-19 */
+
+/* In-place linear -> display encoding of the top-left width x height region of `image`
+ * (editor/editor.cpp:303-340 dispatches it over the swapchain extent on the UI output texture, an RGBA16
+ * UNORM image: editor/uilayer.cpp:285-291; the shader declares `rgba16f`, the resource is UNORM16 — loads and
+ * stores follow the resource). Alpha is passed through. 16 B/px of HBM traffic: HBM-bound. */
+int szg_record_oetf(void* stream, const szg_image* image, uint32_t width, uint32_t height, uint32_t transfer_function);
 
 /* ------------------------------------------------------------------------- */
 /* Multi-GPU composition (no reference counterpart; BASELINE north_star)       */

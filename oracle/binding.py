@@ -47,6 +47,9 @@ def _load(name):
                                        U32, FP, U32, U32, FP, U32, U32, C.c_int]
         h.oracle_gbuffer_fill.argtypes = [P(abi.SceneTexture), abi.Rect, P(abi.RowTile), P(abi.GBuffer), P(abi.CameraPacked),
                                           U32, P(abi.FillScene), C.c_int]
+        h.oracle_aerial_lut.argtypes = [P(abi.AtmospherePacked), U32, P(abi.CameraPacked), U32, FP, U32, U32, U32, U32, U32,
+                                        C.c_float, FP, FP, C.c_int]
+        h.oracle_oetf.argtypes = [P(abi.Image), U32, U32, U32]
         h.oracle_float_to_half.restype = C.c_uint16
         h.oracle_float_to_half.argtypes = [C.c_float]
         h.oracle_half_to_float.restype = C.c_float
@@ -181,3 +184,19 @@ def composite(frame, draw_rect, tile, shadow_maps, atm_packed, cam_packed, dir_l
                            C.byref(shadow_maps) if shadow_maps is not None else None, C.byref(atm_packed), 0,
                            C.byref(cam_packed), 0, C.cast(dir_lights, P(abi.DirectionalLightPacked)), sun_index, fptr(tlut),
                            tlut.shape[1], tlut.shape[0], fptr(slut), slut.shape[1], slut.shape[0], threads)
+
+
+def oetf(color_u16, function):
+    """In-place OETF on a host [h, w, 4] uint16 array."""
+    im = host_image(color_u16, abi.SZG_FORMAT_RGBA16_UNORM)
+    lib().oracle_oetf(C.byref(im), color_u16.shape[1], color_u16.shape[0], function)
+    return color_u16
+
+
+def aerial_lut(atm_packed, cam_packed, tlut, max_distance, dims=(32, 32, 32), threads=1):
+    W, H, D = dims
+    lum = np.zeros((D * H, W, 4), np.float32)
+    tr = np.zeros((D * H, W, 4), np.float32)
+    lib().oracle_aerial_lut(C.byref(atm_packed), 0, C.byref(cam_packed), 0, fptr(tlut), tlut.shape[1], tlut.shape[0], W, H, D,
+                            max_distance, fptr(lum), fptr(tr), threads)
+    return lum, tr

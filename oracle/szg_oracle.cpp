@@ -1589,6 +1589,80 @@ void oracle_gbuffer_fill(const szg_scene_texture* scene, szg_rect drawRect, cons
     });
 }
 
+// Aerial-perspective froxel LUT (include/szg/abi.h): no reference pass, but every texel is the
+// reference's own math at a froxel centre — computeLuminanceScatteringIntegral (common.glinl:364-424) and
+// sampleTransmittanceLUT_Segment (common.glinl:114-136) along the camera.comp:320-328 view ray.
+void oracle_aerial_lut(const szg_atmosphere_packed* atmospheres, uint32_t atmosphereIndex, const szg_camera_packed* cameras,
+                       uint32_t cameraIndex, const float* transmittanceLUT, uint32_t tWidth, uint32_t tHeight, uint32_t W,
+                       uint32_t H, uint32_t D, float maxDistance, float* luminance, float* transmittance, int threads)
+{
+    Atmosphere const atmosphere = load(atmospheres[atmosphereIndex]);
+    szg_camera_packed const& camera = cameras[cameraIndex];
+    TransmittanceLUT const lut{{(const uint8_t*)transmittanceLUT, tWidth, tHeight, tWidth * 16u}, (int)tWidth, (int)tHeight};
+    mat4 const inverseProjection = load(camera.inverseProjection);
+    mat4 const rotation = load(camera.rotation);
+    parallel_rows(H * D, threads, [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t row = r0; row < r1; row++)
+        {
+            uint32_t const j = row % H, k = row / H;
+            for (uint32_t i = 0; i < W; i++)
+            {
+                vec3 position = v3(camera.position) / METERS_PER_MM;
+                position.y *= -1.0f;
+                position.y += atmosphere.planetRadiusMm;
+                vec2 const clipSpaceUV{(((float)i + 0.5f) / (float)W - 0.5f) * 2.0f, (((float)j + 0.5f) / (float)H - 0.5f) * 2.0f};
+                vec4 const directionViewSpace = inverseProjection * vec4{clipSpaceUV.x, clipSpaceUV.y, 1.0f, 1.0f};
+                vec4 const rotated = rotation * directionViewSpace;
+                vec3 direction = normalize(vec3{rotated.x, rotated.y, rotated.z});
+                direction.y *= -1.0f;
+                float const d = (((float)k + 0.5f) / (float)D) * maxDistance;
+                vec3 const lum = computeLuminanceScatteringIntegral(atmosphere, lut, position, direction, d);
+                vec3 const T = sampleTransmittanceLUT_Segment(lut, atmosphere, position, position + d * direction);
+                size_t const id = ((size_t)k * H + j) * W + i;
+                luminance[id * 4 + 0] = lum.x;
+                luminance[id * 4 + 1] = lum.y;
+                luminance[id * 4 + 2] = lum.z;
+                luminance[id * 4 + 3] = 1.0f;
+                transmittance[id * 4 + 0] = T.x;
+                transmittance[id * 4 + 1] = T.y;
+                transmittance[id * 4 + 2] = T.z;
+                transmittance[id * 4 + 3] = 1.0f;
+            }
+        }
+    });
+}
+
+// transfer/oetf_srgb.comp:9-32 and transfer/oetf_pure_gamma.comp:9-22, in place on an RGBA16 UNORM image
+// (the resource format, editor/uilayer.cpp:285-291). function: 0 pure gamma 2.2, 1 sRGB.
+void oracle_oetf(const szg_image* image, uint32_t width, uint32_t height, uint32_t function)
+{
+    for (uint32_t y = 0; y < height; y++)
+    {
+        for (uint32_t x = 0; x < width; x++)
+        {
+            uint16_t* p = (uint16_t*)((uint8_t*)image->data + (size_t)y * image->pitch_bytes) + (size_t)x * 4;
+            for (int c = 0; c < 3; c++)
+            {
+                float const linear = unorm16_load(p[c]);
+                float nonlinear;
+                if (function == 1u)
+                {
+                    bool const cutoff = linear <= 0.0031308f;
+                    float const lower = 12.92f * linear;
+                    float const higher = GL_POW(linear, 1.0f / 2.4f) * 1.055f - 0.055f;
+                    nonlinear = cutoff ? lower : higher; // mix(higher, lower, bvec cutoff)
+                }
+                else
+                {
+                    nonlinear = GL_POW(linear, 1.0f / 2.2f);
+                }
+                p[c] = unorm16_store(nonlinear);
+            }
+            // alpha: imageStore(..., vec4(nonlinear, linear.a)) of a UNORM value loaded from the same texel
+        }
+    }
+}
+
 // The GLSL built-ins as this build evaluates them (pinned fpmath, or libm with
 // -DSZG_ORACLE_LIBM), vectorised for the accuracy tests. fn: 0 exp, 1 pow(x, y), 2 sin,
 // 3 cos, 4 asin, 5 acos.

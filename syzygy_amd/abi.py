@@ -12,6 +12,10 @@ SZG_ABI_VERSION = 1
 
 SZG_OK = 0
 
+SZG_AERIAL_W = SZG_AERIAL_H = SZG_AERIAL_D = 32
+SZG_OETF_PURE_GAMMA = 0
+SZG_OETF_SRGB = 1
+
 SZG_FORMAT_UNDEFINED = 0
 SZG_FORMAT_RGBA16_SFLOAT = 1
 SZG_FORMAT_RGBA32_SFLOAT = 2
@@ -282,6 +286,12 @@ ABI_FUNCTIONS = {
         C.c_int,
         [VP, VP, P(SceneTexture), Rect, P(RowTile), P(GBuffer), P(ShadowMaps), U32, VP, U32, VP, U32, VP],
     ),
+    "szg_skyview_record_aerial_lut": (C.c_int, [VP, VP, U32, VP, U32, VP, C.c_float]),
+    "szg_skyview_aerial_lut": (C.c_int, [VP, P(Image), P(Image)]),
+    "szg_skyview_record_composite_fast": (
+        C.c_int,
+        [VP, VP, P(SceneTexture), Rect, P(RowTile), P(GBuffer), P(ShadowMaps), U32, VP, U32, VP, U32, VP],
+    ),
     "szg_skyview_transmittance_lut": (C.c_int, [VP, P(Image)]),
     "szg_skyview_skyview_lut": (C.c_int, [VP, P(Image)]),
     "szg_deferred_create": (C.c_int, [P(VP), P(DeferredDesc), C.c_int]),
@@ -300,6 +310,7 @@ ABI_FUNCTIONS = {
     "szg_deferred_set_shadow_map": (C.c_int, [VP, U32, P(Image)]),
     "szg_deferred_get_configuration": (C.c_int, [VP, P(DeferredConfiguration)]),
     "szg_deferred_set_configuration": (C.c_int, [VP, P(DeferredConfiguration)]),
+    "szg_record_oetf": (C.c_int, [VP, P(Image), U32, U32, U32]),
     "szg_compose_rowtiles": (C.c_int, [VP, VP, C.c_size_t, U32, U32, P(Image), U32, U32]),
     "szg_rowtile_local_rows": (U32, [U32, U32, U32, U32]),
 }

@@ -111,6 +111,23 @@ struct GBufferPtrsC
     szg_image diffuse, specular, normal, position, orm;
 };
 
+// Trilinear fetch of the aerial-perspective luminance volume at screen position (sx, sy) in [0, 1] and distance
+// `dist` (Mm): clamp-to-edge in x, y; slices at d_k = (k + .5) / D * maxDistance, linear ramp to 0 below d_0.
+SZG_DEV V3 sampleAerial(const AerialLut& A, float sx, float sy, float dist)
+{
+    const float4* vol = reinterpret_cast<const float4*>(A.luminance);
+    float const fz = dist / A.maxDistance * (float)A.D - 0.5f;
+    float const ramp = fz < 0.0f ? fmaxf(dist / (0.5f * A.maxDistance / (float)A.D), 0.0f) : 1.0f;
+    float const z = fminf(fmaxf(fz, 0.0f), (float)A.D - 1.0f);
+    int const k0 = (int)floorf(z);
+    int const k1 = min(k0 + 1, (int)A.D - 1);
+    float const wz = z - (float)k0;
+    V3 const l0 = bilinear_rgb(vol + (size_t)k0 * A.W * A.H, (int)A.W, (int)A.H, (float)A.W, (float)A.H, sx, sy);
+    V3 const l1 = bilinear_rgb(vol + (size_t)k1 * A.W * A.H, (int)A.W, (int)A.H, (float)A.W, (float)A.H, sx, sy);
+    return (l0 * (1.0f - wz) + l1 * wz) * ramp;
+}
+
+template <bool FAST>
 __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image depth, szg_image debug, GBufferPtrsC g,
                                                    unsigned drawW, unsigned drawH, unsigned localRows, RowMap rm,
                                                    ShadowSlot sunSlot, const szg_atmosphere_packed* __restrict__ atmospheres,
@@ -118,7 +135,7 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
                                                    unsigned cameraIndex,
                                                    const szg_directional_light_packed* __restrict__ dirLights,
                                                    unsigned sunLightIndex, const float4* __restrict__ tlut, int tW, int tH,
-                                                   const float4* __restrict__ slut, int sW, int sH)
+                                                   const float4* __restrict__ slut, int sW, int sH, AerialLut aerial)
 {
     unsigned const tid = threadIdx.x;
     unsigned const wave = tid >> 6, lane = tid & 63u;
@@ -243,8 +260,16 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
         float const scalar = (shadowFactor * fractionOfSunVisible) * (shadowedByPlanet ? 0.0f : 1.0f);
         base = ((((scalar * transmittanceToSun) * transmittanceToSurface) * m.occlusion) * brdf) *
                clampf(dot(m.normal, lightDirection), 0.0f, 1.0f);
-        march0 = true;
         l0 = length(surfacePosition - position);
+        if (FAST)
+        {
+            // APPROXIMATE extension (abi.h): aerial perspective from the froxel LUT instead of the inline march
+            base = base + sampleAerial(aerial, (float)x / (float)drawW, (float)gy / (float)drawH, l0);
+        }
+        else
+        {
+            march0 = true;
+        }
 
         // camera.comp:379-386: single-bounce reflection. metallic == 0 makes the
         // whole term an exact zero, so it is skipped.
@@ -334,7 +359,7 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
 hipError_t launch_composite(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
                             const szg_gbuffer& g, ShadowSlot sunSlot, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                             unsigned camIndex, const szg_directional_light_packed* d_dir, unsigned sunIndex, const float* tlut,
-                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH)
+                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH, AerialLut aerial)
 {
     unsigned const rows = tile.nranks <= 1u ? drawH : tile.local_rows;
     if (rows == 0u || drawW == 0u)
@@ -344,10 +369,20 @@ hipError_t launch_composite(hipStream_t s, const szg_scene_texture& scene, unsig
     dim3 const grid((drawW + 31u) / 32u, (rows + 7u) / 8u);
     RowMap const rm{tile.block_rows, tile.rank, tile.nranks};
     GBufferPtrsC const gp{g.diffuse, g.specular, g.normal, g.worldPosition, g.occlusionRoughnessMetallic};
-    hipLaunchKernelGGL(k_composite, grid, dim3(256), 0, s, scene.color, scene.depth, scene.debug_color, gp, drawW, drawH, rows,
-                       rm, sunSlot, d_atm, atmIndex, d_cam, camIndex, d_dir, sunIndex,
-                       reinterpret_cast<const float4*>(tlut), (int)tW, (int)tH, reinterpret_cast<const float4*>(slut), (int)sW,
-                       (int)sH);
+    if (aerial.luminance != nullptr)
+    {
+        hipLaunchKernelGGL(k_composite<true>, grid, dim3(256), 0, s, scene.color, scene.depth, scene.debug_color, gp, drawW, drawH,
+                           rows, rm, sunSlot, d_atm, atmIndex, d_cam, camIndex, d_dir, sunIndex,
+                           reinterpret_cast<const float4*>(tlut), (int)tW, (int)tH, reinterpret_cast<const float4*>(slut),
+                           (int)sW, (int)sH, aerial);
+    }
+    else
+    {
+        hipLaunchKernelGGL(k_composite<false>, grid, dim3(256), 0, s, scene.color, scene.depth, scene.debug_color, gp, drawW, drawH,
+                           rows, rm, sunSlot, d_atm, atmIndex, d_cam, camIndex, d_dir, sunIndex,
+                           reinterpret_cast<const float4*>(tlut), (int)tW, (int)tH, reinterpret_cast<const float4*>(slut),
+                           (int)sW, (int)sH, aerial);
+    }
     return hipGetLastError();
 }
 } // namespace szg

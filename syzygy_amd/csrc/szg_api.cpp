@@ -247,6 +247,9 @@ struct szg_skyview
     szg_skyview_desc desc{};
     float* d_transmittance = nullptr;
     float* d_skyview = nullptr;
+    float* d_aerialLuminance = nullptr;
+    float* d_aerialTransmittance = nullptr;
+    float aerialMaxDistance = 0.0f; // 0 = never recorded
     bool haveTransmittance = false, haveSkyview = false;
 };
 
@@ -349,6 +352,15 @@ int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int de
     {
         e = hipMalloc(reinterpret_cast<void**>(&p->d_skyview), (size_t)d.skyview_width * d.skyview_height * 16u);
     }
+    size_t const aerialBytes = (size_t)SZG_AERIAL_W * SZG_AERIAL_H * SZG_AERIAL_D * 16u;
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_aerialLuminance), aerialBytes);
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_aerialTransmittance), aerialBytes);
+    }
     if (e != hipSuccess)
     {
         szg_skyview_destroy(p);
@@ -372,6 +384,14 @@ void szg_skyview_destroy(szg_skyview_t* p)
     if (p->d_skyview != nullptr)
     {
         (void)hipFree(p->d_skyview);
+    }
+    if (p->d_aerialLuminance != nullptr)
+    {
+        (void)hipFree(p->d_aerialLuminance);
+    }
+    if (p->d_aerialTransmittance != nullptr)
+    {
+        (void)hipFree(p->d_aerialTransmittance);
     }
     delete p;
 }
@@ -441,11 +461,11 @@ int szg_skyview_record_skyview_lut(szg_skyview_t* p, void* stream, uint32_t atmo
                                                p->desc.skyview_height);
 }
 
-int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture, szg_rect draw_rect,
-                                 const szg_rowtile* tile, const szg_gbuffer* gbuffer, const szg_shadowmaps* shadow_maps,
-                                 uint32_t atmosphere_index, const szg_atmosphere_packed* d_atmospheres,
-                                 uint32_t view_camera_index, const szg_camera_packed* d_cameras, uint32_t sun_light_index,
-                                 const szg_directional_light_packed* d_lights)
+static int record_composite(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture, szg_rect draw_rect,
+                            const szg_rowtile* tile, const szg_gbuffer* gbuffer, const szg_shadowmaps* shadow_maps,
+                            uint32_t atmosphere_index, const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                            const szg_camera_packed* d_cameras, uint32_t sun_light_index,
+                            const szg_directional_light_packed* d_lights, bool fast)
 {
     if (p == nullptr || d_atmospheres == nullptr || d_cameras == nullptr || d_lights == nullptr)
     {
@@ -479,10 +499,71 @@ int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene
         slotCount = sun_light_index + 1u;
     }
     (void)slotCount;
+    szg::AerialLut aerial{nullptr, SZG_AERIAL_W, SZG_AERIAL_H, SZG_AERIAL_D, 0.0f};
+    if (fast)
+    {
+        if (!(p->aerialMaxDistance > 0.0f))
+        {
+            return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_composite_fast: no aerial LUT has been recorded");
+        }
+        aerial.luminance = p->d_aerialLuminance;
+        aerial.maxDistance = p->aerialMaxDistance;
+    }
     SZG_HIP(szg::launch_composite(static_cast<hipStream_t>(stream), *scene_texture, draw_rect.width, draw_rect.height, t, *gbuffer,
                                   sun, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, d_lights, sun_light_index,
                                   p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
-                                  p->desc.skyview_width, p->desc.skyview_height));
+                                  p->desc.skyview_width, p->desc.skyview_height, aerial));
+    return SZG_OK;
+}
+
+int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture, szg_rect draw_rect,
+                                 const szg_rowtile* tile, const szg_gbuffer* gbuffer, const szg_shadowmaps* shadow_maps,
+                                 uint32_t atmosphere_index, const szg_atmosphere_packed* d_atmospheres,
+                                 uint32_t view_camera_index, const szg_camera_packed* d_cameras, uint32_t sun_light_index,
+                                 const szg_directional_light_packed* d_lights)
+{
+    return record_composite(p, stream, scene_texture, draw_rect, tile, gbuffer, shadow_maps, atmosphere_index, d_atmospheres,
+                            view_camera_index, d_cameras, sun_light_index, d_lights, false);
+}
+
+int szg_skyview_record_composite_fast(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture, szg_rect draw_rect,
+                                      const szg_rowtile* tile, const szg_gbuffer* gbuffer, const szg_shadowmaps* shadow_maps,
+                                      uint32_t atmosphere_index, const szg_atmosphere_packed* d_atmospheres,
+                                      uint32_t view_camera_index, const szg_camera_packed* d_cameras, uint32_t sun_light_index,
+                                      const szg_directional_light_packed* d_lights)
+{
+    return record_composite(p, stream, scene_texture, draw_rect, tile, gbuffer, shadow_maps, atmosphere_index, d_atmospheres,
+                            view_camera_index, d_cameras, sun_light_index, d_lights, true);
+}
+
+int szg_skyview_record_aerial_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                  const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
+                                  const szg_camera_packed* d_cameras, float max_distance_mm)
+{
+    if (p == nullptr || d_atmospheres == nullptr || d_cameras == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_aerial_lut: NULL argument");
+    }
+    if (!(max_distance_mm > 0.0f) || !(max_distance_mm < 1.0e6f))
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_aerial_lut: max_distance_mm must be in (0, 1e6)");
+    }
+    SZG_HIP(szg::launch_aerial_lut(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, d_cameras, view_camera_index,
+                                   p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height,
+                                   p->d_aerialLuminance, p->d_aerialTransmittance, SZG_AERIAL_W, SZG_AERIAL_H, SZG_AERIAL_D,
+                                   max_distance_mm));
+    p->aerialMaxDistance = max_distance_mm;
+    return SZG_OK;
+}
+
+int szg_skyview_aerial_lut(const szg_skyview_t* p, szg_image* out_luminance, szg_image* out_transmittance)
+{
+    if (p == nullptr || out_luminance == nullptr || out_transmittance == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_aerial_lut: NULL argument");
+    }
+    *out_luminance = make_image(p->d_aerialLuminance, SZG_AERIAL_W, SZG_AERIAL_H * SZG_AERIAL_D, SZG_FORMAT_RGBA32_SFLOAT);
+    *out_transmittance = make_image(p->d_aerialTransmittance, SZG_AERIAL_W, SZG_AERIAL_H * SZG_AERIAL_D, SZG_FORMAT_RGBA32_SFLOAT);
     return SZG_OK;
 }
 
@@ -836,6 +917,32 @@ int szg_deferred_record_draw_commands(szg_deferred_t* p, void* stream, szg_rect 
     return szg_deferred_record_lights(p, stream, draw_rect, tile, scene_texture, atmospheric_directional_lights_count,
                                       d_directional_lights, directional_light_count, h_spot_lights, spot_light_count,
                                       view_camera_index, d_cameras);
+}
+
+int szg_record_oetf(void* stream, const szg_image* image, uint32_t width, uint32_t height, uint32_t transfer_function)
+{
+    if (image == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_record_oetf: image is NULL");
+    }
+    if (transfer_function != SZG_OETF_PURE_GAMMA && transfer_function != SZG_OETF_SRGB)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_record_oetf: unknown transfer function %u", transfer_function);
+    }
+    if (width == 0u || height == 0u)
+    {
+        return SZG_OK;
+    }
+    if (!check_image(*image, SZG_FORMAT_RGBA16_UNORM, width, height, "oetf image"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    if (image->pitch_bytes % 16u != 0u || reinterpret_cast<uintptr_t>(image->data) % 16u != 0u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_record_oetf: image rows must be 16-byte aligned");
+    }
+    SZG_HIP(szg::launch_oetf(static_cast<hipStream_t>(stream), *image, width, height, transfer_function));
+    return SZG_OK;
 }
 
 int szg_compose_rowtiles(void* stream, const void* gathered, size_t tile_stride_bytes, uint32_t nranks, uint32_t block_rows,

@@ -35,6 +35,13 @@ struct ShadowSlot
 };
 static_assert(sizeof(ShadowSlot) == 24, "ShadowSlot layout");
 
+struct AerialLut
+{
+    const float* luminance; // nullptr = exact composite
+    unsigned W, H, D;
+    float maxDistance;
+};
+
 struct TileArgs
 {
     unsigned block_rows, rank, nranks, local_rows;
@@ -58,7 +65,11 @@ hipError_t launch_gbuffer_fill(hipStream_t s, const szg_scene_texture& scene, un
 hipError_t launch_composite(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
                             const szg_gbuffer& g, ShadowSlot sunSlot, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                             unsigned camIndex, const szg_directional_light_packed* d_dir, unsigned sunIndex, const float* tlut,
-                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH);
+                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH, AerialLut aerial);
+hipError_t launch_aerial_lut(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
+                             unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* luminance, float* transmittance,
+                             unsigned W, unsigned H, unsigned D, float maxDistance);
+hipError_t launch_oetf(hipStream_t s, const szg_image& image, unsigned width, unsigned height, unsigned function);
 hipError_t launch_compose_rowtiles(hipStream_t s, const void* gathered, size_t tileStrideBytes, unsigned nranks,
                                    unsigned blockRows, const szg_image& dst, unsigned width, unsigned height);
 } // namespace szg

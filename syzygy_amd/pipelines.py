@@ -139,6 +139,13 @@ class SceneTexture:
         return self.color.cpu().numpy().view(np.uint16)
 
 
+def recordOETF(cmd, sceneTexture, width, height, transferFunction=abi.SZG_OETF_SRGB):
+    """editor.cpp:303-340: in-place linear -> display encoding of the colour image (sRGB by default,
+    editorconfig.hpp:13)."""
+    im = sceneTexture.abi().color
+    check(lib().szg_record_oetf(_stream_handle(cmd), C.byref(im), int(width), int(height), int(transferFunction)))
+
+
 class DeferredShadingPipeline:
     """deferred.hpp:23-119."""
 
@@ -322,6 +329,27 @@ class SkyViewComputePipeline:
             C.byref(gbuffer), C.byref(shadowMaps) if shadowMaps is not None else None, int(atmosphereIndex),
             C.c_void_p(atmospheres.deviceAddress()), int(viewCameraIndex), C.c_void_p(cameras.deviceAddress()),
             int(sunLightIndex), C.c_void_p(lights.deviceAddress())))
+
+    def recordAerialLUT(self, cmd, atmosphereIndex, atmospheres, viewCameraIndex, cameras, maxDistanceMm):
+        """Extension (no reference counterpart, abi.h): aerial-perspective froxel LUT, exact texel values."""
+        check(lib().szg_skyview_record_aerial_lut(self._h, _stream_handle(cmd), int(atmosphereIndex),
+                                                  C.c_void_p(atmospheres.deviceAddress()), int(viewCameraIndex),
+                                                  C.c_void_p(cameras.deviceAddress()), C.c_float(maxDistanceMm)))
+
+    def recordCompositeFast(self, cmd, sceneTexture, drawRect, gbuffer, shadowMaps, atmosphereIndex, atmospheres,
+                            viewCameraIndex, cameras, sunLightIndex, lights, tile=None):
+        """Extension: APPROXIMATE composite (aerial perspective from the froxel LUT). Never part of the parity frame."""
+        st = sceneTexture.abi()
+        check(lib().szg_skyview_record_composite_fast(
+            self._h, _stream_handle(cmd), C.byref(st), drawRect, C.byref(tile) if tile is not None else None,
+            C.byref(gbuffer), C.byref(shadowMaps) if shadowMaps is not None else None, int(atmosphereIndex),
+            C.c_void_p(atmospheres.deviceAddress()), int(viewCameraIndex), C.c_void_p(cameras.deviceAddress()),
+            int(sunLightIndex), C.c_void_p(lights.deviceAddress())))
+
+    def aerialLUT(self):
+        lum, tr = abi.Image(), abi.Image()
+        check(lib().szg_skyview_aerial_lut(self._h, C.byref(lum), C.byref(tr)))
+        return lum, tr
 
     def _lut(self, getter):
         im = abi.Image()

@@ -450,6 +450,99 @@ def test_rowtiles_equal_full_frame_bit_exact(gpu, nranks, block_rows):
     assert (d_out.cpu().numpy().view(np.uint16) == full_q).all()
 
 
+# ---------------------------------------------------------------------------
+# Aerial-perspective froxel LUT (extension without a reference pass). Texel values are the
+# reference's own math at froxel centres -> parity with the oracle. The fast composite that CONSUMES the LUT is
+# approximate by design and only has to stay close to the exact composite.
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("elevation,max_distance", [(35.0, 0.032), (5.0, 0.2)])
+def test_aerial_lut_matches_oracle(gpu, elevation, max_distance):
+    inp = util.Inputs(160, 90, elevation_degrees=elevation)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(512, 128), skyview_extent=(64, 32))
+    tlut = gpu.ob.transmittance_lut(inp.atm, 512, 128, threads=8)
+    sky.upload_lut(sky.transmittanceLUT(), tlut)
+    sky.recordAerialLUT(None, 0, atmospheres, 0, cameras, max_distance)
+    torch.cuda.synchronize()
+    lum_im, tr_im = sky.aerialLUT()
+    assert (lum_im.width, lum_im.height) == (32, 32 * 32)
+    got_lum, got_tr = sky.download_lut(lum_im), sky.download_lut(tr_im)
+    want_lum, want_tr = gpu.ob.aerial_lut(inp.atm, inp.cam, tlut, max_distance, threads=8)
+    assert_close(got_lum, want_lum, atol=1e-12, what="aerial luminance")
+    assert_close(got_tr, want_tr, atol=1e-12, what="aerial transmittance")
+    exact = float((got_lum.view(np.uint32) == want_lum.view(np.uint32)).mean())
+    print(f"aerial LUT elev {elevation}: bit-identical fraction {exact:.4f}")
+    vol = got_lum.reshape(32, 32, 32, 4)
+    if np.isfinite(vol).all():  # (froxel rays longer than the distance to the ground are NaN in the reference math too)
+        assert (vol[1:, :, :, :3].sum((1, 2, 3)) >= vol[:-1, :, :, :3].sum((1, 2, 3))).all()  # in-scatter grows with depth
+    finite = np.isfinite(got_tr[..., :3])
+    assert (got_tr[..., :3][finite] <= 1).all() and (got_tr[..., :3][finite] >= 0).all()
+    sky.destroy()
+
+
+def test_fast_composite_is_close_to_the_exact_one(gpu):
+    W, H = 320, 180
+    inp = util.Inputs(W, H, elevation_degrees=35.0, spots=8)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    exact_t = gpu.pl.SceneTexture(W, H, debug=True)
+    fast_t = gpu.pl.SceneTexture(W, H, debug=True)
+    deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=8, max_shadow_maps=0)
+    sky = gpu.pl.SkyViewComputePipeline.create(skyview_extent=(512, 256))
+    for target in (exact_t, fast_t):
+        deferred.recordDrawCommands(None, inp.rect, target, 1, lights, inp.spots, 0, cameras, inp.synthetic.fill)
+    sky.recordTransmittance(None, 0, atmospheres)
+    sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    from syzygy_amd import SzgError
+
+    with pytest.raises(SzgError):  # no aerial LUT yet
+        sky.recordCompositeFast(None, fast_t, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    sky.recordAerialLUT(None, 0, atmospheres, 0, cameras, 10.0e-3)  # 10 km
+    sky.recordComposite(None, exact_t, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    sky.recordCompositeFast(None, fast_t, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    a, b = exact_t.debug.cpu().numpy(), fast_t.debug.cpu().numpy()
+    geo = (exact_t.depth.cpu().numpy() > 0)
+    assert (a[~geo].view(np.uint32) == b[~geo].view(np.uint32)).all(), "sky pixels must be untouched by the fast mode"
+    rel = util.rel_err(a[geo][:, :3], b[geo][:, :3], util.ATOL_COLOR)
+    print(f"fast composite vs exact: max rel {rel.max():.3e}, mean rel {rel.mean():.3e} over {geo.sum()} geometry pixels")
+    assert rel.max() < 5e-2 and rel.mean() < 5e-3
+    deferred.cleanup()
+    sky.destroy()
+
+
+# ---------------------------------------------------------------------------
+# OETF: integer in, integer out -> bit-exact
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("function", [0, 1])
+@pytest.mark.parametrize("size", [(256, 64), (131, 7), (1, 1)])
+def test_oetf_bit_exact(gpu, function, size):
+    W, H = size
+    rng = np.random.default_rng(W * 31 + function)
+    img = rng.integers(0, 65536, (H, W, 4), dtype=np.uint16)
+    img[0, 0] = [0, 205, 206, 65535]  # around the sRGB cutoff 0.0031308 * 65535 = 205.2
+    pad = 5 + (-(W + 5) % 2)  # a target wider than the region, rows still 16-byte multiples
+    target = gpu.pl.SceneTexture(W + pad, H + 3)
+    target.color.fill_(-12345)
+    target.color[:H, :W] = torch.from_numpy(img.view(np.int16)).cuda()
+    gpu.pl.recordOETF(None, target, W, H, function)
+    torch.cuda.synchronize()
+    got = target.color_numpy()
+    want = gpu.ob.oetf(img.copy(), function)
+    assert (got[:H, :W] == want).all()
+    assert (got[:H, :W, 3] == img[..., 3]).all()  # alpha passes through
+    untouched = np.int16(-12345).astype(np.int16).view(np.uint16)
+    assert (got[H:] == untouched).all() and (got[:, W:] == untouched).all()
+
+
+def test_oetf_known_values(gpu):
+    img = np.zeros((1, 4, 4), np.uint16)
+    img[0, :, 0] = [0, 65535, 32768, 100]
+    out = gpu.ob.oetf(img.copy(), 1)
+    assert out[0, 0, 0] == 0 and out[0, 1, 0] == 65535
+    assert abs(out[0, 2, 0] / 65535 - (1.055 * 0.5000076 ** (1 / 2.4) - 0.055)) < 2e-5
+    assert out[0, 3, 0] == round(12.92 * 100)  # linear segment below the cutoff
+
+
 def test_empty_draw_rect_is_a_no_op(gpu):
     inp = util.Inputs(32, 32, spots=1)
     cameras, atmospheres, lights = staged(gpu, inp)
