@@ -354,6 +354,21 @@ int szg_skyview_record_composite_fast(szg_skyview_t* p, void* stream, const szg_
                                       const szg_camera_packed* d_cameras, uint32_t sun_light_index,
                                       const szg_directional_light_packed* d_lights);
 
+/* ---- Multi-scattering LUT (north_star item) ---------------------------------------------------
+ * NO reference counterpart (the only trace is the unused constant phaseIsotropic, common.glinl:281-282), so there
+ * is no reference parity: "parity unpinned". Build-defined after Hillaire 2020 section 5.5: SZG_MULTISCATTER_DIM^2
+ * texels over (u = 0.5 + 0.5 cos(sun zenith), v = altitude / atmosphere thickness); per texel 64 sphere directions
+ * (8 x 8 stratified), each a 20-step march accumulating the 2nd-order in-scattered luminance L2 and the transfer
+ * factor f_ms with the reference's own extinction / sun-transmittance functions (common.glinl:145-216) and the
+ * ground term of camera.comp:203-227 (albedo 0.4 / pi); texel = mean(L2) / (1 - mean(f_ms)). One 64-lane wavefront
+ * per texel, lane = direction, butterfly reduction across the wave. Opt-in and NOT consumed by any parity pass:
+ * adding it to the scattering integral would change results. Validated against the scalar oracle
+ * (same reduction tree) and by energy sanity (0 <= f_ms < 1). */
+#define SZG_MULTISCATTER_DIM 32u
+int szg_skyview_record_multiscatter_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                        const szg_atmosphere_packed* d_atmospheres);
+int szg_skyview_multiscatter_lut(const szg_skyview_t* p, szg_image* out);
+
 /* Accessors to the LUT images the pipeline owns (skyview.hpp:52-97 `map`). */
 int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out);
 int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out);

@@ -47,6 +47,7 @@ def _load(name):
                                        U32, FP, U32, U32, FP, U32, U32, C.c_int]
         h.oracle_gbuffer_fill.argtypes = [P(abi.SceneTexture), abi.Rect, P(abi.RowTile), P(abi.GBuffer), P(abi.CameraPacked),
                                           U32, P(abi.FillScene), C.c_int]
+        h.oracle_multiscatter_lut.argtypes = [P(abi.AtmospherePacked), U32, FP, U32, U32, U32, FP, FP]
         h.oracle_aerial_lut.argtypes = [P(abi.AtmospherePacked), U32, P(abi.CameraPacked), U32, FP, U32, U32, U32, U32, U32,
                                         C.c_float, FP, FP, C.c_int]
         h.oracle_oetf.argtypes = [P(abi.Image), U32, U32, U32]
@@ -200,3 +201,10 @@ def aerial_lut(atm_packed, cam_packed, tlut, max_distance, dims=(32, 32, 32), th
     lib().oracle_aerial_lut(C.byref(atm_packed), 0, C.byref(cam_packed), 0, fptr(tlut), tlut.shape[1], tlut.shape[0], W, H, D,
                             max_distance, fptr(lum), fptr(tr), threads)
     return lum, tr
+
+
+def multiscatter_lut(atm_packed, tlut, dim=32):
+    out = np.zeros((dim, dim, 4), np.float32)
+    fms = np.zeros((dim, dim, 4), np.float32)
+    lib().oracle_multiscatter_lut(C.byref(atm_packed), 0, fptr(tlut), tlut.shape[1], tlut.shape[0], dim, fptr(out), fptr(fms))
+    return out, fms

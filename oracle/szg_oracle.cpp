@@ -1589,6 +1589,98 @@ void oracle_gbuffer_fill(const szg_scene_texture* scene, szg_rect drawRect, cons
     });
 }
 
+// Multi-scattering LUT (include/szg/abi.h): BUILD-DEFINED, no reference counterpart ("parity
+// unpinned"); this is the scalar statement of the definition in abi.h, after Hillaire 2020 section 5.5, built from
+// the reference's own sampleExtinction / sampleTransmittanceLUT_Sun. The 64 per-direction values are summed with
+// the same butterfly tree as the GPU's wave reduction so that both give identical bits.
+void oracle_multiscatter_lut(const szg_atmosphere_packed* atmospheres, uint32_t atmosphereIndex, const float* transmittanceLUT,
+                             uint32_t tWidth, uint32_t tHeight, uint32_t dim, float* out, float* out_fms)
+{
+    Atmosphere const atmosphere = load(atmospheres[atmosphereIndex]);
+    TransmittanceLUT const lut{{(const uint8_t*)transmittanceLUT, tWidth, tHeight, tWidth * 16u}, (int)tWidth, (int)tHeight};
+    float const isotropic = 1.0f / (4.0f * PI); // common.glinl:282
+    auto treeSum = [](float* v) {
+        for (int off = 1; off < 64; off <<= 1)
+        {
+            float w[64];
+            for (int l = 0; l < 64; l++)
+            {
+                w[l] = v[l] + v[l ^ off];
+            }
+            std::memcpy(v, w, sizeof w);
+        }
+        return v[0];
+    };
+    for (uint32_t ty = 0; ty < dim; ty++)
+    {
+        for (uint32_t tx = 0; tx < dim; tx++)
+        {
+            float const cosSunZenith = (((float)tx + 0.5f) / (float)dim) * 2.0f - 1.0f;
+            float const radius =
+                atmosphere.planetRadiusMm + (((float)ty + 0.5f) / (float)dim) * (atmosphere.atmosphereRadiusMm - atmosphere.planetRadiusMm);
+            vec3 const sunDir{safeSqrt(1.0f - cosSunZenith * cosSunZenith), cosSunZenith, 0.0f};
+            vec3 const pos{0.0f, radius, 0.0f};
+            float L2[3][64], F[3][64];
+            for (uint32_t lane = 0; lane < 64; lane++)
+            {
+                float const theta = 2.0f * PI * (((float)(lane & 7u) + 0.5f) / 8.0f);
+                float const cosPhi = 1.0f - 2.0f * (((float)(lane >> 3) + 0.5f) / 8.0f);
+                float const sinPhi = safeSqrt(1.0f - cosPhi * cosPhi);
+                vec3 const dir{GL_COS(theta) * sinPhi, cosPhi, GL_SIN(theta) * sinPhi};
+                float tMax;
+                raycastAtmosphere(atmosphere, pos, dir, tMax);
+                float gt0 = 0.0f, gt1 = 0.0f;
+                bool const hitGround = raySphereIntersection(pos, dir, atmosphere.planetRadiusMm, gt0, gt1) && gt0 > 0.0f;
+                vec3 l2 = vec3(0.0f), fms = vec3(0.0f), Tacc = vec3(1.0f);
+                float const dt = tMax / 20.0f;
+                for (int i = 0; i < 20; i++)
+                {
+                    float const t = ((float)i + 0.5f) * dt;
+                    vec3 const p = pos + t * dir;
+                    float const r = length(p);
+                    ExtinctionSample const ex = sampleExtinction(atmosphere, r - atmosphere.planetRadiusMm);
+                    vec3 const sigma_s = ex.scatteringRayleigh + ex.scatteringMie;
+                    float const mu_s = dot(p, sunDir) / r;
+                    vec3 const T_sun = sampleTransmittanceLUT_Sun(lut, atmosphere, r, mu_s);
+                    vec3 const T_step = exp3(-dt * ex.extinction);
+                    vec3 const S = sigma_s * T_sun * isotropic;
+                    l2 += Tacc * ((S - S * T_step) / ex.extinction);
+                    fms += Tacc * ((sigma_s - sigma_s * T_step) / ex.extinction);
+                    Tacc *= T_step;
+                }
+                if (hitGround)
+                {
+                    vec3 const pg = pos + tMax * dir;
+                    vec3 const n = normalize(pg);
+                    float const NdotL = clampf(dot(n, sunDir), 0.0f, 1.0f);
+                    float const rg = length(pg);
+                    float const mu_g = dot(pg, sunDir) / rg;
+                    vec3 const T_sun = sampleTransmittanceLUT_Sun(lut, atmosphere, rg, mu_g);
+                    l2 += Tacc * T_sun * (NdotL * (0.4f / PI));
+                }
+                L2[0][lane] = l2.x; L2[1][lane] = l2.y; L2[2][lane] = l2.z;
+                F[0][lane] = fms.x; F[1][lane] = fms.y; F[2][lane] = fms.z;
+            }
+            float* o = out + ((size_t)ty * dim + tx) * 4;
+            for (int c = 0; c < 3; c++)
+            {
+                float const meanL = treeSum(L2[c]) / 64.0f;
+                float const meanF = treeSum(F[c]) / 64.0f;
+                o[c] = meanL / (1.0f - meanF);
+                if (out_fms != nullptr)
+                {
+                    out_fms[((size_t)ty * dim + tx) * 4 + c] = meanF;
+                }
+            }
+            o[3] = 1.0f;
+            if (out_fms != nullptr)
+            {
+                out_fms[((size_t)ty * dim + tx) * 4 + 3] = 1.0f;
+            }
+        }
+    }
+}
+
 // Aerial-perspective froxel LUT (include/szg/abi.h): no reference pass, but every texel is the
 // reference's own math at a froxel centre — computeLuminanceScatteringIntegral (common.glinl:364-424) and
 // sampleTransmittanceLUT_Segment (common.glinl:114-136) along the camera.comp:320-328 view ray.

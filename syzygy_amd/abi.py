@@ -286,6 +286,8 @@ ABI_FUNCTIONS = {
         C.c_int,
         [VP, VP, P(SceneTexture), Rect, P(RowTile), P(GBuffer), P(ShadowMaps), U32, VP, U32, VP, U32, VP],
     ),
+    "szg_skyview_record_multiscatter_lut": (C.c_int, [VP, VP, U32, VP]),
+    "szg_skyview_multiscatter_lut": (C.c_int, [VP, P(Image)]),
     "szg_skyview_record_aerial_lut": (C.c_int, [VP, VP, U32, VP, U32, VP, C.c_float]),
     "szg_skyview_aerial_lut": (C.c_int, [VP, P(Image), P(Image)]),
     "szg_skyview_record_composite_fast": (

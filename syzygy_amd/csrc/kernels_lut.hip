@@ -222,6 +222,96 @@ hipError_t launch_aerial_lut(hipStream_t s, const szg_atmosphere_packed* d_atm, 
     return hipGetLastError();
 }
 
+// Multi-scattering LUT (include/szg/abi.h "Multi-scattering LUT"; extension, no reference counterpart).
+// One wavefront per texel, one sphere direction per lane, butterfly reduction over the 64 lanes.
+SZG_DEV float waveSum64(float v)
+{
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1)
+    {
+        v = v + __shfl_xor(v, off); // every lane ends with the same tree sum ((l ^ off) partner, commutative add)
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void k_multiscatter(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
+                                                     const float4* __restrict__ tlut, int tW, int tH, float4* __restrict__ out,
+                                                     unsigned dim)
+{
+    unsigned const tx = blockIdx.x, ty = blockIdx.y, lane = threadIdx.x;
+    Atm const a = load_atm(atmospheres + atmosphereIndex);
+    TLut const L = make_tlut(tlut, tW, tH);
+    float const PI = 3.141592653589793f;
+
+    float const cosSunZenith = (((float)tx + 0.5f) / (float)dim) * 2.0f - 1.0f;
+    float const radius = a.planetRadius + (((float)ty + 0.5f) / (float)dim) * (a.atmosphereRadius - a.planetRadius);
+    V3 const sunDir = mk3(safeSqrt(1.0f - cosSunZenith * cosSunZenith), cosSunZenith, 0.0f);
+    V3 const pos = mk3(0.0f, radius, 0.0f);
+
+    // 8 x 8 stratified sphere directions
+    float const theta = 2.0f * PI * (((float)(lane & 7u) + 0.5f) / 8.0f);
+    float const cosPhi = 1.0f - 2.0f * (((float)(lane >> 3) + 0.5f) / 8.0f);
+    float const sinPhi = safeSqrt(1.0f - cosPhi * cosPhi);
+    V3 const dir = mk3(szg_cosf(theta) * sinPhi, cosPhi, szg_sinf(theta) * sinPhi);
+
+    float const tMax = raycastAtmosphere(a, pos, dir);
+    float gt0 = 0.0f, gt1 = 0.0f;
+    bool const hitGround = raySphere(pos, dir, a.planetRadius, gt0, gt1) && gt0 > 0.0f;
+
+    float const sin_sunRadius = szg_sinf(a.sunAngularRadius);
+    float const cos_sunRadius = szg_cosf(a.sunAngularRadius);
+    float const isotropic = 1.0f / (4.0f * PI); // common.glinl:282
+    V3 L2 = splat(0.0f), fms = splat(0.0f), Tacc = splat(1.0f);
+    float const dt = tMax / 20.0f;
+    for (int i = 0; i < 20; i++)
+    {
+        float const t = ((float)i + 0.5f) * dt;
+        V3 const p = pos + t * dir;
+        float const r = length(p);
+        Extinction const ex = sampleExtinction(a, r - a.planetRadius);
+        V3 const sigma_s = ex.scatteringRayleigh + ex.scatteringMie;
+        float const mu_s = dot(p, sunDir) / r;
+        // sampleTransmittanceLUT_Sun, common.glinl:145-172
+        float const sin_hz = a.planetRadius / r;
+        float const cos_hz = -safeSqrt(1.0f - sin_hz * sin_hz);
+        V3 const T_sun = sampleT_RadiusMu(L, a, r, mu_s) * smoothstep(-sin_hz * sin_sunRadius, sin_hz * sin_sunRadius, mu_s - cos_hz * cos_sunRadius);
+        V3 const T_step = mk3(szg_expf(-dt * ex.extinction.x), szg_expf(-dt * ex.extinction.y), szg_expf(-dt * ex.extinction.z));
+        V3 const S = sigma_s * T_sun * isotropic;
+        L2 = L2 + Tacc * ((S - S * T_step) / ex.extinction);
+        fms = fms + Tacc * ((sigma_s - sigma_s * T_step) / ex.extinction);
+        Tacc = Tacc * T_step;
+    }
+    if (hitGround)
+    {
+        V3 const pg = pos + tMax * dir;
+        V3 const n = normalize(pg);
+        float const NdotL = clampf(dot(n, sunDir), 0.0f, 1.0f);
+        float const rg = length(pg);
+        float const mu_g = dot(pg, sunDir) / rg;
+        float const sin_hz = a.planetRadius / rg;
+        float const cos_hz = -safeSqrt(1.0f - sin_hz * sin_hz);
+        V3 const T_sun = sampleT_RadiusMu(L, a, rg, mu_g) * smoothstep(-sin_hz * sin_sunRadius, sin_hz * sin_sunRadius, mu_g - cos_hz * cos_sunRadius);
+        L2 = L2 + Tacc * T_sun * (NdotL * (0.4f / PI)); // camera.comp:218 ground albedo
+    }
+    V3 const sumL = mk3(waveSum64(L2.x), waveSum64(L2.y), waveSum64(L2.z));
+    V3 const sumF = mk3(waveSum64(fms.x), waveSum64(fms.y), waveSum64(fms.z));
+    if (lane == 0u)
+    {
+        V3 const meanL = sumL / 64.0f;
+        V3 const meanF = sumF / 64.0f;
+        V3 const psi = meanL / (splat(1.0f) - meanF);
+        out[ty * dim + tx] = make_float4(psi.x, psi.y, psi.z, 1.0f);
+    }
+}
+
+hipError_t launch_multiscatter(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const float* tlut, unsigned tW,
+                               unsigned tH, float* out, unsigned dim)
+{
+    hipLaunchKernelGGL(k_multiscatter, dim3(dim, dim), dim3(64), 0, s, d_atm, atmIndex, reinterpret_cast<const float4*>(tlut), (int)tW,
+                       (int)tH, reinterpret_cast<float4*>(out), dim);
+    return hipGetLastError();
+}
+
 hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, float* lut, unsigned W,
                                 unsigned H)
 {

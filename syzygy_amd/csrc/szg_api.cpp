@@ -247,6 +247,7 @@ struct szg_skyview
     szg_skyview_desc desc{};
     float* d_transmittance = nullptr;
     float* d_skyview = nullptr;
+    float* d_multiscatter = nullptr;
     float* d_aerialLuminance = nullptr;
     float* d_aerialTransmittance = nullptr;
     float aerialMaxDistance = 0.0f; // 0 = never recorded
@@ -355,6 +356,10 @@ int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int de
     size_t const aerialBytes = (size_t)SZG_AERIAL_W * SZG_AERIAL_H * SZG_AERIAL_D * 16u;
     if (e == hipSuccess)
     {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_multiscatter), (size_t)SZG_MULTISCATTER_DIM * SZG_MULTISCATTER_DIM * 16u);
+    }
+    if (e == hipSuccess)
+    {
         e = hipMalloc(reinterpret_cast<void**>(&p->d_aerialLuminance), aerialBytes);
     }
     if (e == hipSuccess)
@@ -384,6 +389,10 @@ void szg_skyview_destroy(szg_skyview_t* p)
     if (p->d_skyview != nullptr)
     {
         (void)hipFree(p->d_skyview);
+    }
+    if (p->d_multiscatter != nullptr)
+    {
+        (void)hipFree(p->d_multiscatter);
     }
     if (p->d_aerialLuminance != nullptr)
     {
@@ -534,6 +543,29 @@ int szg_skyview_record_composite_fast(szg_skyview_t* p, void* stream, const szg_
 {
     return record_composite(p, stream, scene_texture, draw_rect, tile, gbuffer, shadow_maps, atmosphere_index, d_atmospheres,
                             view_camera_index, d_cameras, sun_light_index, d_lights, true);
+}
+
+int szg_skyview_record_multiscatter_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
+                                        const szg_atmosphere_packed* d_atmospheres)
+{
+    if (p == nullptr || d_atmospheres == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_multiscatter_lut: NULL argument");
+    }
+    SZG_HIP(szg::launch_multiscatter(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, p->d_transmittance,
+                                     p->desc.transmittance_width, p->desc.transmittance_height, p->d_multiscatter,
+                                     SZG_MULTISCATTER_DIM));
+    return SZG_OK;
+}
+
+int szg_skyview_multiscatter_lut(const szg_skyview_t* p, szg_image* out)
+{
+    if (p == nullptr || out == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_multiscatter_lut: NULL argument");
+    }
+    *out = make_image(p->d_multiscatter, SZG_MULTISCATTER_DIM, SZG_MULTISCATTER_DIM, SZG_FORMAT_RGBA32_SFLOAT);
+    return SZG_OK;
 }
 
 int szg_skyview_record_aerial_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,

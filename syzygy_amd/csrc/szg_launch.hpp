@@ -69,6 +69,8 @@ hipError_t launch_composite(hipStream_t s, const szg_scene_texture& scene, unsig
 hipError_t launch_aerial_lut(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                              unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* luminance, float* transmittance,
                              unsigned W, unsigned H, unsigned D, float maxDistance);
+hipError_t launch_multiscatter(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const float* tlut, unsigned tW,
+                               unsigned tH, float* out, unsigned dim);
 hipError_t launch_oetf(hipStream_t s, const szg_image& image, unsigned width, unsigned height, unsigned function);
 hipError_t launch_compose_rowtiles(hipStream_t s, const void* gathered, size_t tileStrideBytes, unsigned nranks,
                                    unsigned blockRows, const szg_image& dst, unsigned width, unsigned height);

@@ -330,6 +330,14 @@ class SkyViewComputePipeline:
             C.c_void_p(atmospheres.deviceAddress()), int(viewCameraIndex), C.c_void_p(cameras.deviceAddress()),
             int(sunLightIndex), C.c_void_p(lights.deviceAddress())))
 
+    def recordMultiScatterLUT(self, cmd, atmosphereIndex, atmospheres):
+        """Extension (no reference counterpart, abi.h): multi-scattering LUT, one wavefront per texel."""
+        check(lib().szg_skyview_record_multiscatter_lut(self._h, _stream_handle(cmd), int(atmosphereIndex),
+                                                        C.c_void_p(atmospheres.deviceAddress())))
+
+    def multiScatterLUT(self):
+        return self._lut(lib().szg_skyview_multiscatter_lut)
+
     def recordAerialLUT(self, cmd, atmosphereIndex, atmospheres, viewCameraIndex, cameras, maxDistanceMm):
         """Extension (no reference counterpart, abi.h): aerial-perspective froxel LUT, exact texel values."""
         check(lib().szg_skyview_record_aerial_lut(self._h, _stream_handle(cmd), int(atmosphereIndex),

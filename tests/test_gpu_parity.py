@@ -511,6 +511,25 @@ def test_fast_composite_is_close_to_the_exact_one(gpu):
 
 
 # ---------------------------------------------------------------------------
+# Multi-scattering LUT: extension, "parity unpinned" (no reference counterpart) -> own oracle
+# ---------------------------------------------------------------------------
+def test_multiscatter_lut_matches_its_oracle(gpu):
+    inp = util.Inputs(64, 64, elevation_degrees=35.0)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(512, 128), skyview_extent=(64, 32))
+    tlut = gpu.ob.transmittance_lut(inp.atm, 512, 128, threads=8)
+    sky.upload_lut(sky.transmittanceLUT(), tlut)
+    sky.recordMultiScatterLUT(None, 0, atmospheres)
+    torch.cuda.synchronize()
+    got = sky.download_lut(sky.multiScatterLUT())
+    want, fms = gpu.ob.multiscatter_lut(inp.atm, tlut)
+    assert got.shape == (32, 32, 4)
+    assert_close(got, want, atol=1e-12, what="multi-scattering LUT")
+    print(f"multi-scatter LUT: bit-identical fraction {float((got.view(np.uint32) == want.view(np.uint32)).mean()):.4f}")
+    sky.destroy()
+
+
+# ---------------------------------------------------------------------------
 # OETF: integer in, integer out -> bit-exact
 # ---------------------------------------------------------------------------
 @pytest.mark.parametrize("function", [0, 1])
