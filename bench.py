@@ -35,7 +35,8 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 WORKLOADS = {
-    "c2": dict(width=1920, height=1080, spots=0, tiled=False, label="C2 1920x1080 sun+moon, sky-view composite, 0 spots"),
+    "c2": dict(width=1920, height=1080, spots=0, tiled=False, sun_shadow=2048,
+               label="C2 1920x1080 sun (composite, one 2048^2 analytic sun shadow map) + moon (lights pass), 0 spots"),
     "c3": dict(width=3840, height=2160, spots=64, tiled=False,
                label="C3 3840x2160 full atmosphere (LUTs 512x128 + 2048x1024 recomputed per frame) + 64 spot lights"),
     "c4": dict(width=7680, height=4320, spots=64, tiled=True,
@@ -106,13 +107,16 @@ def main():
         b.recordCopyToDevice()
 
     target = pl.SceneTexture(W, max(stride_rows, 1), dev)
-    deferred = pl.DeferredShadingPipeline((W, max(rows, 1)), max_spot_lights=max(SPOTS, 1), max_shadow_maps=0,
-                                          device_index=local_rank)
+    sun_shadow = wl.get("sun_shadow", 0)
+    deferred = pl.DeferredShadingPipeline((W, max(rows, 1)), max_spot_lights=max(SPOTS, 1), max_shadow_maps=1 if sun_shadow else 0,
+                                          shadow_map_dim=sun_shadow, device_index=local_rank)
     sky = pl.SkyViewComputePipeline.create(device_index=local_rank)
     assert sky is not None
     rect = pl.rect(W, H)
-    # G-buffer fill: producer of the synthetic input, outside the timed region
+    # G-buffer fill and shadow-map generation: producers of the path's inputs, outside the timed region
     deferred.recordGBufferFill(None, rect, target, 0, cameras, syn.fill, tile=tile)
+    if sun_shadow:
+        deferred.recordShadowMaps(None, lights, None, syn.fill)
     torch.cuda.synchronize()
     geometry_px_local = int((target.depth[:rows] > 0).sum().item())
 

@@ -425,6 +425,18 @@ int szg_deferred_record_lights(szg_deferred_t* p, void* stream, szg_rect draw_re
                                uint32_t spot_light_count, uint32_t view_camera_index,
                                const szg_camera_packed* d_cameras);
 
+/* Shadow-map generation: the depth-only pass of shadowpass.cpp:188-270 +
+ * offscreenpass/depthpass.vert:30-38 + pipelines.cpp:640-663 (front-face culling, reverse-Z, GREATER_OR_EQUAL,
+ * clear to 0 = far) for the ANALYTIC scene: per texel centre the light's ray is cast against the boxes of
+ * `geometry` and the depth of the nearest BACK face (what front-face culling leaves) is stored; the ground plane,
+ * single-sided and facing the lights, is culled exactly as in the raster pass. Slots run directional lights [0, n)
+ * then spot lights, capped at max_shadow_maps (shadowpass.cpp:219-225). Only maps the pipeline owns
+ * (shadow_map_dim > 0) are written; the depth bias of szg_deferred_configuration is stored but not applied
+ * (rasteriser-specific units). Called by szg_deferred_record_draw_commands when geometry != NULL. */
+int szg_deferred_record_shadow_maps(szg_deferred_t* p, void* stream, const szg_directional_light_packed* d_directional_lights,
+                                    uint32_t directional_light_count, const szg_spot_light_packed* h_spot_lights,
+                                    uint32_t spot_light_count, const szg_fill_scene* geometry);
+
 /* deferred.hpp:46-47 gbuffer() / shadowMaps(). Pointers stay valid until destroy. */
 const szg_gbuffer* szg_deferred_gbuffer(szg_deferred_t* p);
 const szg_shadowmaps* szg_deferred_shadow_maps(szg_deferred_t* p);

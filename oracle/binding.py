@@ -47,6 +47,7 @@ def _load(name):
                                        U32, FP, U32, U32, FP, U32, U32, C.c_int]
         h.oracle_gbuffer_fill.argtypes = [P(abi.SceneTexture), abi.Rect, P(abi.RowTile), P(abi.GBuffer), P(abi.CameraPacked),
                                           U32, P(abi.FillScene), C.c_int]
+        h.oracle_shadow_map.argtypes = [P(abi.Mat4), P(abi.Mat4), U32, P(abi.FillScene), FP, C.c_int]
         h.oracle_multiscatter_lut.argtypes = [P(abi.AtmospherePacked), U32, FP, U32, U32, U32, FP, FP]
         h.oracle_aerial_lut.argtypes = [P(abi.AtmospherePacked), U32, P(abi.CameraPacked), U32, FP, U32, U32, U32, U32, U32,
                                         C.c_float, FP, FP, C.c_int]
@@ -208,3 +209,10 @@ def multiscatter_lut(atm_packed, tlut, dim=32):
     fms = np.zeros((dim, dim, 4), np.float32)
     lib().oracle_multiscatter_lut(C.byref(atm_packed), 0, fptr(tlut), tlut.shape[1], tlut.shape[0], dim, fptr(out), fptr(fms))
     return out, fms
+
+
+def shadow_map(light, dim, fill_scene, threads=1):
+    """Depth map of the analytic scene from `light` (a packed directional or spot light)."""
+    out = np.zeros((dim, dim), np.float32)
+    lib().oracle_shadow_map(C.byref(light.projection), C.byref(light.view), dim, C.byref(fill_scene), fptr(out), threads)
+    return out

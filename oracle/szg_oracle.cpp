@@ -1589,6 +1589,110 @@ void oracle_gbuffer_fill(const szg_scene_texture* scene, szg_rect drawRect, cons
     });
 }
 
+// glm::inverse(mat4) (cofactor expansion), the operation order of syzygy_amd/csrc/host_scene.cpp.
+static mat4 inverse4(const mat4& m)
+{
+    auto M = [&](int c, int r) { return m.m[c * 4 + r]; };
+    float const C00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3), C02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3),
+                C03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3), C04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3),
+                C06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3), C07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3),
+                C08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2), C10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2),
+                C11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2), C12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3),
+                C14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3), C15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3),
+                C16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2), C18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2),
+                C19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2), C20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1),
+                C22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1), C23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+    float const F0[4] = {C00, C00, C02, C03}, F1[4] = {C04, C04, C06, C07}, F2[4] = {C08, C08, C10, C11},
+                F3[4] = {C12, C12, C14, C15}, F4[4] = {C16, C16, C18, C19}, F5[4] = {C20, C20, C22, C23};
+    float const V0[4] = {M(1, 0), M(0, 0), M(0, 0), M(0, 0)}, V1[4] = {M(1, 1), M(0, 1), M(0, 1), M(0, 1)},
+                V2[4] = {M(1, 2), M(0, 2), M(0, 2), M(0, 2)}, V3[4] = {M(1, 3), M(0, 3), M(0, 3), M(0, 3)};
+    float const SA[4] = {1.0f, -1.0f, 1.0f, -1.0f}, SB[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+    mat4 inv;
+    for (int i = 0; i < 4; i++)
+    {
+        inv.m[0 * 4 + i] = (V1[i] * F0[i] - V2[i] * F1[i] + V3[i] * F2[i]) * SA[i];
+        inv.m[1 * 4 + i] = (V0[i] * F0[i] - V2[i] * F3[i] + V3[i] * F4[i]) * SB[i];
+        inv.m[2 * 4 + i] = (V0[i] * F1[i] - V1[i] * F3[i] + V3[i] * F5[i]) * SA[i];
+        inv.m[3 * 4 + i] = (V0[i] * F2[i] - V1[i] * F4[i] + V2[i] * F5[i]) * SB[i];
+    }
+    float const det = (M(0, 0) * inv.m[0] + M(0, 1) * inv.m[4]) + (M(0, 2) * inv.m[8] + M(0, 3) * inv.m[12]);
+    float const ood = 1.0f / det;
+    for (float& f : inv.m)
+    {
+        f = f * ood;
+    }
+    return inv;
+}
+
+// Shadow-map generation for the analytic scene (abi.h szg_deferred_record_shadow_maps):
+// depth-only pass of shadowpass.cpp:188-270 / depthpass.vert:30-38 with the raster state of pipelines.cpp:640-663
+// (front faces culled, reverse-Z, GREATER_OR_EQUAL, clear 0). out: dim * dim floats.
+void oracle_shadow_map(const szg_mat4* projection, const szg_mat4* view, uint32_t dim, const szg_fill_scene* geometry, float* out,
+                       int threads)
+{
+    mat4 const pv = load(*projection) * load(*view);
+    mat4 const inv = inverse4(pv);
+    parallel_rows(dim, threads, [&](uint32_t r0, uint32_t r1) {
+        for (uint32_t y = r0; y < r1; y++)
+        {
+            for (uint32_t x = 0; x < dim; x++)
+            {
+                float const ndcx = (((float)x + 0.5f) / (float)dim) * 2.0f - 1.0f;
+                float const ndcy = (((float)y + 0.5f) / (float)dim) * 2.0f - 1.0f;
+                vec4 const h1 = inv * vec4{ndcx, ndcy, 1.0f, 1.0f};
+                vec4 const h2 = inv * vec4{ndcx, ndcy, 0.5f, 1.0f};
+                vec3 const p1{h1.x / h1.w, h1.y / h1.w, h1.z / h1.w};
+                vec3 const p2{h2.x / h2.w, h2.y / h2.w, h2.z / h2.w};
+                vec3 const dir = normalize(p2 - p1);
+                float const o[3] = {p1.x, p1.y, p1.z};
+                float const d[3] = {dir.x, dir.y, dir.z};
+                float best = 0.0f;
+                for (uint32_t b = 0; b < geometry->box_count; b++)
+                {
+                    szg_fill_box const& box = geometry->boxes[b];
+                    float tmin = -3.0e38f, tmax = 3.0e38f;
+                    bool miss = false;
+                    for (int a = 0; a < 3; a++)
+                    {
+                        float const lo = box.center[a] - box.half_extent[a];
+                        float const hi = box.center[a] + box.half_extent[a];
+                        if (d[a] == 0.0f)
+                        {
+                            if (o[a] < lo || o[a] > hi)
+                            {
+                                miss = true;
+                            }
+                            continue;
+                        }
+                        float t0 = (lo - o[a]) / d[a];
+                        float t1 = (hi - o[a]) / d[a];
+                        if (t0 > t1)
+                        {
+                            float const tmp = t0;
+                            t0 = t1;
+                            t1 = tmp;
+                        }
+                        tmin = fmaxf(tmin, t0);
+                        tmax = fminf(tmax, t1);
+                    }
+                    if (miss || tmin > tmax || tmax <= 0.0f)
+                    {
+                        continue;
+                    }
+                    vec3 const pe = p1 + tmax * dir;
+                    vec4 const clip = pv * vec4{pe.x, pe.y, pe.z, 1.0f};
+                    float const depth = clip.z / clip.w;
+                    if (depth > 0.0f && depth <= 1.0f && depth >= best)
+                    {
+                        best = depth;
+                    }
+                }
+                out[(size_t)y * dim + x] = best;
+            }
+        }
+    });
+}
+
 // Multi-scattering LUT (include/szg/abi.h): BUILD-DEFINED, no reference counterpart ("parity
 // unpinned"); this is the scalar statement of the definition in abi.h, after Hillaire 2020 section 5.5, built from
 // the reference's own sampleExtinction / sampleTransmittanceLUT_Sun. The 64 per-direction values are summed with

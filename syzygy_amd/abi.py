@@ -307,6 +307,7 @@ ABI_FUNCTIONS = {
         C.c_int,
         [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, U32, P(SpotLightPacked), U32, U32, VP],
     ),
+    "szg_deferred_record_shadow_maps": (C.c_int, [VP, VP, VP, U32, P(SpotLightPacked), U32, P(FillScene)]),
     "szg_deferred_gbuffer": (P(GBuffer), [VP]),
     "szg_deferred_shadow_maps": (P(ShadowMaps), [VP]),
     "szg_deferred_set_shadow_map": (C.c_int, [VP, U32, P(Image)]),

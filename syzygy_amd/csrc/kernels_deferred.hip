@@ -466,6 +466,122 @@ __global__ __launch_bounds__(256) void k_compose(const uint4* __restrict__ gathe
 }
 
 // ---------------------------------------------------------------------------
+// Shadow-map generation for the analytic scene (abi.h szg_deferred_record_shadow_maps).
+__global__ void k_shadow_prep(const szg_directional_light_packed* __restrict__ dirs, unsigned dirCount,
+                              const szg_spot_light_packed* __restrict__ spots, unsigned spotCount,
+                              const ShadowSlot* __restrict__ owned, unsigned slotCount, ShadowGen* __restrict__ gen)
+{
+    unsigned const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= slotCount)
+    {
+        return;
+    }
+    ShadowGen g;
+    g.map = nullptr;
+    g.dim = g.pitchFloats = g.pad = 0u;
+    M4 pv;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        pv.m[k] = 0.0f;
+    }
+    if (i < dirCount + spotCount && owned[i].map != nullptr)
+    {
+        // light.projection * light.view (shadowpass.cpp:207-215)
+        pv = (i < dirCount) ? mul(load_m4(dirs[i].projection), load_m4(dirs[i].view))
+                            : mul(load_m4(spots[i - dirCount].projection), load_m4(spots[i - dirCount].view));
+        g.map = const_cast<float*>(owned[i].map);
+        g.dim = owned[i].width;
+        g.pitchFloats = owned[i].pitchFloats;
+    }
+    M4 const inv = inverse4(pv);
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        g.projView[k] = pv.m[k];
+        g.invProjView[k] = inv.m[k];
+    }
+    gen[i] = g;
+}
+
+__global__ __launch_bounds__(256) void k_shadow_fill(const ShadowGen* __restrict__ gen, const szg_fill_box* __restrict__ boxes,
+                                                     unsigned boxCount)
+{
+    const ShadowGen* G = gen + blockIdx.z;
+    if (G->map == nullptr)
+    {
+        return;
+    }
+    unsigned x, y;
+    pixel_of_thread(x, y);
+    unsigned const dim = G->dim;
+    if (x >= dim || y >= dim)
+    {
+        return;
+    }
+    M4 pv, inv;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        pv.m[k] = G->projView[k];
+        inv.m[k] = G->invProjView[k];
+    }
+    // texel centre -> NDC (inverse of TO_TEX_COORD_MAT, shadowmap.glinl:2-7): s = 0.5 ndc + 0.5
+    float const ndcx = (((float)x + 0.5f) / (float)dim) * 2.0f - 1.0f;
+    float const ndcy = (((float)y + 0.5f) / (float)dim) * 2.0f - 1.0f;
+    V4 const h1 = mul(inv, ndcx, ndcy, 1.0f, 1.0f); // reverse-Z: depth 1 = near plane
+    V4 const h2 = mul(inv, ndcx, ndcy, 0.5f, 1.0f);
+    V3 const p1 = mk3(h1.x / h1.w, h1.y / h1.w, h1.z / h1.w);
+    V3 const p2 = mk3(h2.x / h2.w, h2.y / h2.w, h2.z / h2.w);
+    V3 const dir = normalize(p2 - p1);
+    float const o[3] = {p1.x, p1.y, p1.z};
+    float const d[3] = {dir.x, dir.y, dir.z};
+    float best = 0.0f; // cleared depth = far
+    for (unsigned b = 0; b < boxCount; b++)
+    {
+        szg_fill_box const box = boxes[b];
+        float tmin = -3.0e38f, tmax = 3.0e38f;
+        bool miss = false;
+#pragma unroll
+        for (int ax = 0; ax < 3; ax++)
+        {
+            float const lo = box.center[ax] - box.half_extent[ax];
+            float const hi = box.center[ax] + box.half_extent[ax];
+            if (d[ax] == 0.0f)
+            {
+                if (o[ax] < lo || o[ax] > hi)
+                {
+                    miss = true;
+                }
+                continue;
+            }
+            float t0 = (lo - o[ax]) / d[ax];
+            float t1 = (hi - o[ax]) / d[ax];
+            if (t0 > t1)
+            {
+                float const tmp = t0;
+                t0 = t1;
+                t1 = tmp;
+            }
+            tmin = fmaxf(tmin, t0);
+            tmax = fminf(tmax, t1);
+        }
+        if (miss || tmin > tmax || tmax <= 0.0f)
+        {
+            continue;
+        }
+        V3 const pe = p1 + tmax * dir; // back face: what front-face culling leaves (pipelines.cpp:656-659)
+        V4 const clip = mul(pv, pe.x, pe.y, pe.z, 1.0f);
+        float const depth = clip.z / clip.w;
+        if (depth > 0.0f && depth <= 1.0f && depth >= best) // GREATER_OR_EQUAL (pipelines.cpp:661)
+        {
+            best = depth;
+        }
+    }
+    G->map[(size_t)y * G->pitchFloats + x] = best;
+}
+
+// ---------------------------------------------------------------------------
 // transfer/oetf_srgb.comp:9-19, transfer/oetf_pure_gamma.comp:9 — in place on RGBA16 UNORM. Two pixels (16 B)
 // per lane per access, fully coalesced; 16 B/px of traffic against three pow() per pixel.
 SZG_DEV float oetf(float linear, unsigned function)
@@ -567,6 +683,21 @@ hipError_t launch_lights(hipStream_t s, const szg_scene_texture& scene, unsigned
     dim3 const grid((drawW + 31u) / 32u, (rows + 7u) / 8u);
     hipLaunchKernelGGL(k_lights, grid, dim3(256), 0, s, scene.color, scene.debug_color, gptrs(g), drawW, rows, d_cam, camIndex,
                        d_lights, lightCount);
+    return hipGetLastError();
+}
+
+hipError_t launch_shadow_maps(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount,
+                              const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_ownedSlots,
+                              unsigned slotCount, ShadowGen* d_gen, const szg_fill_box* d_boxes, unsigned boxCount, unsigned maxDim)
+{
+    if (slotCount == 0u || maxDim == 0u)
+    {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_shadow_prep, dim3((slotCount + 63u) / 64u), dim3(64), 0, s, d_dir, dirCount, d_spot, spotCount, d_ownedSlots,
+                       slotCount, d_gen);
+    hipLaunchKernelGGL(k_shadow_fill, dim3((maxDim + 31u) / 32u, (maxDim + 7u) / 8u, slotCount), dim3(256), 0, s, d_gen, d_boxes,
+                       boxCount);
     return hipGetLastError();
 }
 

@@ -267,6 +267,8 @@ struct szg_deferred
     szg_spot_light_packed* d_spots = nullptr;
     szg::ShadowSlot* d_slots = nullptr;
     szg::LightRec* d_lightRecs = nullptr;
+    szg::ShadowSlot* d_ownedSlots = nullptr; // the maps the pipeline allocated itself (never changes after create)
+    szg::ShadowGen* d_shadowGen = nullptr;
     szg_fill_box* d_boxes = nullptr;
     unsigned maxBoxes = 1024;
     unsigned maxDirectional = 16;
@@ -688,6 +690,18 @@ int szg_deferred_create(szg_deferred_t** out, const szg_deferred_desc* desc, int
     {
         e = hipMalloc(reinterpret_cast<void**>(&p->d_boxes), (size_t)p->maxBoxes * sizeof(szg_fill_box));
     }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_ownedSlots), (size_t)nSlots * sizeof(szg::ShadowSlot));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMemset(p->d_ownedSlots, 0, (size_t)nSlots * sizeof(szg::ShadowSlot));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_shadowGen), (size_t)nSlots * sizeof(szg::ShadowGen));
+    }
     p->shadowImages.assign(desc->max_shadow_maps, szg_image{nullptr, 0u, 0u, 0u, SZG_FORMAT_D32_SFLOAT});
     if (e == hipSuccess && desc->shadow_map_dim > 0u && desc->max_shadow_maps > 0u)
     {
@@ -701,11 +715,15 @@ int szg_deferred_create(szg_deferred_t** out, const szg_deferred_desc* desc, int
         }
         if (e == hipSuccess)
         {
+            std::vector<szg::ShadowSlot> owned(desc->max_shadow_maps);
             for (unsigned i = 0; i < desc->max_shadow_maps; i++)
             {
                 p->shadowImages[i] = make_image(static_cast<unsigned char*>(p->d_ownedShadowMaps) + one * i, desc->shadow_map_dim,
                                                 desc->shadow_map_dim, SZG_FORMAT_D32_SFLOAT);
+                owned[i] = szg::ShadowSlot{static_cast<const float*>(p->shadowImages[i].data), desc->shadow_map_dim,
+                                           desc->shadow_map_dim, desc->shadow_map_dim, 0u};
             }
+            e = hipMemcpy(p->d_ownedSlots, owned.data(), owned.size() * sizeof(szg::ShadowSlot), hipMemcpyHostToDevice);
         }
     }
     if (e != hipSuccess)
@@ -755,7 +773,7 @@ void szg_deferred_destroy(szg_deferred_t* p)
             (void)hipFree(plane);
         }
     }
-    void* const rest[] = {p->d_ownedShadowMaps, p->d_spots, p->d_slots, p->d_lightRecs, p->d_boxes};
+    void* const rest[] = {p->d_ownedShadowMaps, p->d_spots, p->d_slots, p->d_lightRecs, p->d_boxes, p->d_ownedSlots, p->d_shadowGen};
     for (void* r : rest)
     {
         if (r != nullptr)
@@ -930,6 +948,53 @@ int szg_deferred_record_lights(szg_deferred_t* p, void* stream, szg_rect draw_re
     return SZG_OK;
 }
 
+int szg_deferred_record_shadow_maps(szg_deferred_t* p, void* stream, const szg_directional_light_packed* d_directional_lights,
+                                    uint32_t directional_light_count, const szg_spot_light_packed* h_spot_lights,
+                                    uint32_t spot_light_count, const szg_fill_scene* geometry)
+{
+    if (p == nullptr || geometry == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_shadow_maps: NULL argument");
+    }
+    if ((directional_light_count > 0u && d_directional_lights == nullptr) || (spot_light_count > 0u && h_spot_lights == nullptr))
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_shadow_maps: light array NULL");
+    }
+    if (spot_light_count > p->desc.max_spot_lights)
+    {
+        return fail(SZG_ERR_CAPACITY, "szg_deferred_record_shadow_maps: %u spot lights exceed the capacity %u", spot_light_count,
+                    p->desc.max_spot_lights);
+    }
+    if (geometry->box_count > p->maxBoxes || (geometry->box_count > 0u && geometry->boxes == nullptr))
+    {
+        return fail(SZG_ERR_CAPACITY, "szg_deferred_record_shadow_maps: %u boxes (capacity %u)", geometry->box_count, p->maxBoxes);
+    }
+    if (p->d_ownedShadowMaps == nullptr)
+    {
+        return SZG_OK; // the pipeline owns no shadow maps (shadow_map_dim == 0): nothing to render into
+    }
+    unsigned const lights = directional_light_count + spot_light_count;
+    unsigned const slots = lights < p->desc.max_shadow_maps ? lights : p->desc.max_shadow_maps; // shadowpass.cpp:219-225
+    if (slots == 0u)
+    {
+        return SZG_OK;
+    }
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    int rc = p->staging.upload(s, p->d_spots, h_spot_lights, (size_t)spot_light_count * sizeof(szg_spot_light_packed));
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    rc = p->staging.upload(s, p->d_boxes, geometry->boxes, (size_t)geometry->box_count * sizeof(szg_fill_box));
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    SZG_HIP(szg::launch_shadow_maps(s, d_directional_lights, directional_light_count, p->d_spots, spot_light_count, p->d_ownedSlots,
+                                    slots, p->d_shadowGen, p->d_boxes, geometry->box_count, p->desc.shadow_map_dim));
+    return SZG_OK;
+}
+
 int szg_deferred_record_draw_commands(szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
                                       const szg_scene_texture* scene_texture, uint32_t atmospheric_directional_lights_count,
                                       const szg_directional_light_packed* d_directional_lights,
@@ -939,8 +1004,14 @@ int szg_deferred_record_draw_commands(szg_deferred_t* p, void* stream, szg_rect 
 {
     if (geometry != nullptr)
     {
-        int const rc =
-            szg_deferred_record_gbuffer_fill(p, stream, draw_rect, tile, scene_texture, view_camera_index, d_cameras, geometry);
+        // deferred.cpp:480-490 shadow maps, then :493-713 the G-buffer pass
+        int rc = szg_deferred_record_shadow_maps(p, stream, d_directional_lights, directional_light_count, h_spot_lights,
+                                                 spot_light_count, geometry);
+        if (rc != SZG_OK)
+        {
+            return rc;
+        }
+        rc = szg_deferred_record_gbuffer_fill(p, stream, draw_rect, tile, scene_texture, view_camera_index, d_cameras, geometry);
         if (rc != SZG_OK)
         {
             return rc;

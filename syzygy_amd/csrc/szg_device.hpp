@@ -150,6 +150,42 @@ SZG_DEV M4 mul(const M4& a, const M4& b)
     }
     return r;
 }
+// glm::inverse(mat4) (cofactor expansion, glm/detail/func_matrix.inl), same operation order as host_scene.cpp
+SZG_DEV M4 inverse4(const M4& m)
+{
+    auto M = [&](int c, int r) { return m.m[c * 4 + r]; };
+    float const C00 = M(2, 2) * M(3, 3) - M(3, 2) * M(2, 3), C02 = M(1, 2) * M(3, 3) - M(3, 2) * M(1, 3),
+                C03 = M(1, 2) * M(2, 3) - M(2, 2) * M(1, 3), C04 = M(2, 1) * M(3, 3) - M(3, 1) * M(2, 3),
+                C06 = M(1, 1) * M(3, 3) - M(3, 1) * M(1, 3), C07 = M(1, 1) * M(2, 3) - M(2, 1) * M(1, 3),
+                C08 = M(2, 1) * M(3, 2) - M(3, 1) * M(2, 2), C10 = M(1, 1) * M(3, 2) - M(3, 1) * M(1, 2),
+                C11 = M(1, 1) * M(2, 2) - M(2, 1) * M(1, 2), C12 = M(2, 0) * M(3, 3) - M(3, 0) * M(2, 3),
+                C14 = M(1, 0) * M(3, 3) - M(3, 0) * M(1, 3), C15 = M(1, 0) * M(2, 3) - M(2, 0) * M(1, 3),
+                C16 = M(2, 0) * M(3, 2) - M(3, 0) * M(2, 2), C18 = M(1, 0) * M(3, 2) - M(3, 0) * M(1, 2),
+                C19 = M(1, 0) * M(2, 2) - M(2, 0) * M(1, 2), C20 = M(2, 0) * M(3, 1) - M(3, 0) * M(2, 1),
+                C22 = M(1, 0) * M(3, 1) - M(3, 0) * M(1, 1), C23 = M(1, 0) * M(2, 1) - M(2, 0) * M(1, 1);
+    float const F0[4] = {C00, C00, C02, C03}, F1[4] = {C04, C04, C06, C07}, F2[4] = {C08, C08, C10, C11},
+                F3[4] = {C12, C12, C14, C15}, F4[4] = {C16, C16, C18, C19}, F5[4] = {C20, C20, C22, C23};
+    float const V0[4] = {M(1, 0), M(0, 0), M(0, 0), M(0, 0)}, V1[4] = {M(1, 1), M(0, 1), M(0, 1), M(0, 1)},
+                V2[4] = {M(1, 2), M(0, 2), M(0, 2), M(0, 2)}, V3_[4] = {M(1, 3), M(0, 3), M(0, 3), M(0, 3)};
+    float const SA[4] = {1.0f, -1.0f, 1.0f, -1.0f}, SB[4] = {-1.0f, 1.0f, -1.0f, 1.0f};
+    M4 inv;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+        inv.m[0 * 4 + i] = (V1[i] * F0[i] - V2[i] * F1[i] + V3_[i] * F2[i]) * SA[i];
+        inv.m[1 * 4 + i] = (V0[i] * F0[i] - V2[i] * F3[i] + V3_[i] * F4[i]) * SB[i];
+        inv.m[2 * 4 + i] = (V0[i] * F1[i] - V1[i] * F3[i] + V3_[i] * F5[i]) * SA[i];
+        inv.m[3 * 4 + i] = (V0[i] * F2[i] - V1[i] * F4[i] + V2[i] * F5[i]) * SB[i];
+    }
+    float const det = (M(0, 0) * inv.m[0] + M(0, 1) * inv.m[4]) + (M(0, 2) * inv.m[8] + M(0, 3) * inv.m[12]);
+    float const ood = 1.0f / det;
+#pragma unroll
+    for (int i = 0; i < 16; i++)
+    {
+        inv.m[i] = inv.m[i] * ood;
+    }
+    return inv;
+}
 SZG_DEV M4 load_m4(const szg_mat4& s)
 {
     M4 r;

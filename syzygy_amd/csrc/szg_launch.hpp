@@ -71,6 +71,17 @@ hipError_t launch_aerial_lut(hipStream_t s, const szg_atmosphere_packed* d_atm, 
                              unsigned W, unsigned H, unsigned D, float maxDistance);
 hipError_t launch_multiscatter(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const float* tlut, unsigned tW,
                                unsigned tH, float* out, unsigned dim);
+// Per-slot state for shadow-map generation, built on the device by k_shadow_prep.
+struct ShadowGen
+{
+    float projView[16];
+    float invProjView[16];
+    float* map; // nullptr = skip
+    unsigned dim, pitchFloats, pad;
+};
+hipError_t launch_shadow_maps(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount,
+                              const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_ownedSlots,
+                              unsigned slotCount, ShadowGen* d_gen, const szg_fill_box* d_boxes, unsigned boxCount, unsigned maxDim);
 hipError_t launch_oetf(hipStream_t s, const szg_image& image, unsigned width, unsigned height, unsigned function);
 hipError_t launch_compose_rowtiles(hipStream_t s, const void* gathered, size_t tileStrideBytes, unsigned nranks,
                                    unsigned blockRows, const szg_image& dst, unsigned width, unsigned height);

@@ -186,6 +186,13 @@ class DeferredShadingPipeline:
             int(atmosphericDirectionalLightsCount), C.c_void_p(directionalLights.deviceAddress()),
             int(directionalLights.deviceSize()), spots, n_spot, int(viewCameraIndex), C.c_void_p(cameras.deviceAddress())))
 
+    def recordShadowMaps(self, cmd, directionalLights, spotLights, sceneGeometry):
+        """render the pipeline-owned shadow maps for the analytic scene."""
+        n_spot = len(spotLights) if spotLights is not None else 0
+        spots = C.cast(spotLights, C.POINTER(abi.SpotLightPacked)) if n_spot else None
+        check(lib().szg_deferred_record_shadow_maps(self._h, _stream_handle(cmd), C.c_void_p(directionalLights.deviceAddress()),
+                                                    int(directionalLights.deviceSize()), spots, n_spot, C.byref(sceneGeometry)))
+
     def gbuffer(self):
         return lib().szg_deferred_gbuffer(self._h).contents
 

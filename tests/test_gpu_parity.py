@@ -511,6 +511,60 @@ def test_fast_composite_is_close_to_the_exact_one(gpu):
 
 
 # ---------------------------------------------------------------------------
+# shadow-map generation for the analytic scene and a frame that uses the maps
+# ---------------------------------------------------------------------------
+def test_shadow_maps_match_oracle_and_shade_the_frame(gpu):
+    W, H, DIM, SPOTS = 192, 108, 256, 3
+    inp = util.Inputs(W, H, elevation_degrees=40.0, spots=SPOTS)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    target = gpu.pl.SceneTexture(W, H, debug=True)
+    deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=SPOTS, max_shadow_maps=2 + SPOTS, shadow_map_dim=DIM)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(256, 64), skyview_extent=(256, 128))
+    # recordDrawCommands: shadow maps -> G-buffer -> lights (deferred.cpp:480-787)
+    deferred.recordDrawCommands(None, inp.rect, target, 1, lights, inp.spots, 0, cameras, inp.synthetic.fill)
+    sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    got = target.debug.cpu().numpy()
+    got_q = target.color_numpy()
+
+    # oracle: the same maps, slot order sun, moon, spots (lights.comp:138-161)
+    packed = [inp.sun, inp.moon] + [inp.spots[i] for i in range(SPOTS)]
+    maps = [gpu.ob.shadow_map(light, DIM, inp.synthetic.fill, threads=8) for light in packed]
+    sm = deferred.shadowMaps()
+    assert sm.count == 2 + SPOTS
+    from syzygy_amd.pipelines import _memcpy2d_from
+
+    for slot, want in enumerate(maps):
+        im = sm.maps[slot]
+        assert (im.width, im.height) == (DIM, DIM)
+        dev = _memcpy2d_from(im, DIM * 4, DIM).cpu().numpy().view(np.float32).reshape(DIM, DIM)
+        assert (dev.view(np.uint32) == want.view(np.uint32)).all(), f"shadow map slot {slot}"
+    assert (maps[0] > 0).any() and (maps[2] > 0).any()
+
+    images = (gpu.abi.Image * len(maps))(*[gpu.ob.host_image(m, gpu.abi.SZG_FORMAT_D32_SFLOAT) for m in maps])
+    host_maps = gpu.abi.ShadowMaps(len(maps), 0, C.cast(images, C.POINTER(gpu.abi.Image)))
+    frame = gpu.ob.HostFrame(W, H)
+    gpu.ob.gbuffer_fill(frame, inp.rect, None, inp.cam, inp.synthetic.fill, threads=8)
+    gpu.ob.lights(frame, inp.rect, None, host_maps, inp.cam, inp.dirs, 2, 1, inp.spots, SPOTS, threads=8)
+    tlut = gpu.ob.transmittance_lut(inp.atm, 256, 64, threads=8)
+    slut = gpu.ob.skyview_lut(inp.atm, inp.cam, tlut, 256, 128, threads=8)
+    gpu.ob.composite(frame, inp.rect, None, host_maps, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=8)
+    assert_close(got, frame.debug, what="frame with generated shadow maps")
+    assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+
+    # and the shadows do something: the same frame without maps is brighter
+    deferred2 = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=SPOTS, max_shadow_maps=0)
+    target2 = gpu.pl.SceneTexture(W, H, debug=True)
+    deferred2.recordDrawCommands(None, inp.rect, target2, 1, lights, inp.spots, 0, cameras, inp.synthetic.fill)
+    sky.recordComposite(None, target2, inp.rect, deferred2.gbuffer(), deferred2.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    assert target2.debug.cpu().numpy()[..., :3].sum() > got[..., :3].sum()
+    deferred.cleanup()
+    deferred2.cleanup()
+    sky.destroy()
+
+
+# ---------------------------------------------------------------------------
 # Multi-scattering LUT: extension, "parity unpinned" (no reference counterpart) -> own oracle
 # ---------------------------------------------------------------------------
 def test_multiscatter_lut_matches_its_oracle(gpu):
