@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_transmittance(const szg_atmosphere_pack
 
 // 256-thread workgroups covering 32x8 texels (each wave an 8x8 patch, so the
 // four transmittance-LUT taps of neighbouring lanes share cache lines).
-__global__ __launch_bounds__(256) void k_skyview(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
+__global__ __launch_bounds__(256, 4) void k_skyview(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
                                                  const szg_camera_packed* __restrict__ cameras, unsigned cameraIndex,
                                                  const float4* __restrict__ tlut, int tW, int tH, float4* __restrict__ lut,
                                                  int W, int H, int rowBegin, int rowEnd)

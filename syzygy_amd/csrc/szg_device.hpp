@@ -120,6 +120,10 @@ template <bool LEAN> SZG_DEV float sqrtX(float x) { return LEAN ? sqrtN(x) : sqr
 template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
 template <bool LEAN> SZG_DEV float divX(float a, float b) { return LEAN ? divN(a, b) : a / b; }
 template <bool LEAN> SZG_DEV float divRX(float a, float b, float y) { return LEAN ? divR(a, b, y) : a / b; }
+SZG_DEV float xorSign(float x, unsigned signMask)
+{
+    return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) ^ signMask);
+}
 SZG_DEV bool inRange(float x, float lo, float hi) { return x >= lo && x <= hi; } // false for NaN
 
 // column-major 4x4 times (x, y, z, w), rows summed left to right
@@ -528,8 +532,11 @@ SZG_DEV V3 segmentRatio(const TLut& L, const Atm& a, const RadiusPart& pFrom, fl
     bool const flip = fromDotDir < 0.0f;
     float const muFrom = divX<LEAN>(fromDotDir, lenFrom * lenDir);
     float const muTo = divX<LEAN>(toDotDir, lenTo * lenDir);
-    V3 const Tf = sampleT_at<LEAN>(L, a, pFrom, flip ? -muFrom : muFrom);
-    V3 const Tt = sampleT_at<LEAN>(L, a, pTo, flip ? -muTo : muTo);
+    // flip ? -mu : mu as a sign-bit XOR (one VALU op instead of a compare/select pair through VCC); for the
+    // ratio, numerator and denominator are swapped by selecting the operands once rather than two quotients
+    unsigned const signFlip = flip ? 0x80000000u : 0u;
+    V3 const Tf = sampleT_at<LEAN>(L, a, pFrom, xorSign(muFrom, signFlip));
+    V3 const Tt = sampleT_at<LEAN>(L, a, pTo, xorSign(muTo, signFlip));
     V3 const q = flip ? (Tt / Tf) : (Tf / Tt);
     return clamp01(q);
 }
@@ -611,7 +618,7 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         Extinction const ex = sampleExtinction<LEAN>(a, altitude);
 
         // sampleTransmittanceLUT_RayMarchStep, common.glinl:336-361
-        V3 const T_end = sampleT_at<LEAN>(L, a, pStep, m.up ? s_mu : -s_mu);
+        V3 const T_end = sampleT_at<LEAN>(L, a, pStep, xorSign(s_mu, m.up ? 0u : 0x80000000u));
         V3 const ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
         V3 const T_begin = (t < 0.0000001f) ? splat(1.0f) : ratio;
 
