@@ -59,6 +59,8 @@ def main():
     ap.add_argument("--workload", default="auto", choices=["auto"] + sorted(WORKLOADS))
     ap.add_argument("--elevation", type=float, default=35.0, help="sun elevation in degrees")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-tiled", action="store_true",
+                    help="testing: run the row-tiled code path (collectives, compose) even with a single rank")
     ap.add_argument("--cpu-rows", type=int, default=540, help="rows of the frame the CPU baseline shades")
     args = ap.parse_args()
 
@@ -72,8 +74,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or args.force_tiled:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import __graft_entry__ as entry
@@ -84,7 +87,7 @@ def main():
     name = args.workload if args.workload != "auto" else ("c3" if args.gpus == 1 else "c4")
     wl = WORKLOADS[name]
     W, H, SPOTS = wl["width"], wl["height"], wl["spots"]
-    tiled = wl["tiled"] and world > 1
+    tiled = wl["tiled"] and (world > 1 or args.force_tiled)
     nranks = world if tiled else 1
     tile = rowtile.make_tile(H, rank, nranks, BLOCK_ROWS)
     rows = tile.local_rows if tile is not None else H
@@ -106,7 +109,10 @@ def main():
     for b in (cameras, atmospheres, lights):
         b.recordCopyToDevice()
 
-    target = pl.SceneTexture(W, max(stride_rows, 1), dev)
+    # Two frames in flight like the reference (framebuffer.cpp:134): frame k renders into targets[k % 2] while the
+    # tile gather of frame k-1 is still on the wire.
+    targets = [pl.SceneTexture(W, max(stride_rows, 1), dev) for _ in range(2 if tiled else 1)]
+    target = targets[0]
     sun_shadow = wl.get("sun_shadow", 0)
     deferred = pl.DeferredShadingPipeline((W, max(rows, 1)), max_spot_lights=max(SPOTS, 1), max_shadow_maps=1 if sun_shadow else 0,
                                           shadow_map_dim=sun_shadow, device_index=local_rank)
@@ -114,7 +120,8 @@ def main():
     assert sky is not None
     rect = pl.rect(W, H)
     # G-buffer fill and shadow-map generation: producers of the path's inputs, outside the timed region
-    deferred.recordGBufferFill(None, rect, target, 0, cameras, syn.fill, tile=tile)
+    for t in targets:
+        deferred.recordGBufferFill(None, rect, t, 0, cameras, syn.fill, tile=tile)
     if sun_shadow:
         deferred.recordShadowMaps(None, lights, None, syn.fill)
     torch.cuda.synchronize()
@@ -122,41 +129,61 @@ def main():
 
     gathered = composed = None
     if tiled and rank == 0:
-        gathered = torch.empty((nranks, stride_rows, W, 4), dtype=torch.int16, device=dev)
+        gathered = [torch.empty((nranks, stride_rows, W, 4), dtype=torch.int16, device=dev) for _ in range(2)]
         composed = torch.empty((H, W, 4), dtype=torch.int16, device=dev)
 
     sky_lut = sky.skyviewLUT_tensor() if tiled else None
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
     spot_arg = spots if SPOTS else None
+    pending = []  # (gathered buffer, work) of the previous frame's tile gather
 
-    def frame(events=None):
+    def finish_gather():
+        while pending:
+            buf, work = pending.pop(0)
+            work.wait()  # the compute stream waits for the collective; the host does not block
+            if rank == 0:
+                rowtile.compose(buf, H, nranks, BLOCK_ROWS, out=composed)
+
+    def frame(k, events=None):
         e = events
+        tgt = targets[k % len(targets)]
         if e:
             e[0].record()
-        deferred.recordLights(None, rect, target, 1, lights, spot_arg, 0, cameras, tile=tile)
-        if e:
-            e[1].record()
-        sky.recordTransmittance(None, 0, atmospheres)
-        if e:
-            e[2].record()
+        lut_work = None
         if tiled:
-            # every rank computes 1/N of the sky-view LUT rows, then one all-gather (texels are independent)
+            # LUTs first: every rank computes 1/N of the sky-view LUT rows, and the all-gather of the slices runs
+            # while the lights pass (which needs no LUT) is shading
+            sky.recordTransmittance(None, 0, atmospheres)
             b, en = rowtile.lut_rows(sky_lut.shape[0], rank, nranks)
             sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, b, en)
-            rowtile.allgather_lut(sky_lut, rank, nranks)
+            lut_work = rowtile.allgather_lut(sky_lut, rank, nranks, async_op=True, force=True)
+            if e:
+                e[1].record()
+                e[2].record()
+            deferred.recordLights(None, rect, tgt, 1, lights, spot_arg, 0, cameras, tile=tile)
+            if e:
+                e[3].record()
+            lut_work.wait()
         else:
+            deferred.recordLights(None, rect, tgt, 1, lights, spot_arg, 0, cameras, tile=tile)
+            if e:
+                e[1].record()
+            sky.recordTransmittance(None, 0, atmospheres)
+            if e:
+                e[2].record()
             sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
-        if e:
-            e[3].record()
-        sky.recordComposite(None, target, rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0,
+            if e:
+                e[3].record()
+        sky.recordComposite(None, tgt, rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0,
                             lights, tile=tile)
         if e:
             e[4].record()
         if tiled:
-            # the one collective of the path: gather the RGBA16 row tiles on rank 0 (RCCL over xGMI)
-            rowtile.gather_tiles(target.color, rank, nranks, gathered=gathered)
-            if rank == 0:
-                rowtile.compose(gathered, H, nranks, BLOCK_ROWS, out=composed)
+            # the gather of frame k-1 has had a whole frame of compute to finish: compose it now, then start ours
+            finish_gather()
+            buf, work = rowtile.gather_tiles(tgt.color, rank, nranks, gathered=gathered[k % 2] if rank == 0 else None,
+                                             async_op=True)
+            pending.append((buf, work))
         if e:
             e[5].record()
 
@@ -166,12 +193,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        frame()
+    for k in range(args.warmup):
+        frame(k)
+    finish_gather()
     sync_all()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        frame(ev[k])
+        frame(k, ev[k])
+    finish_gather()  # the last frame's gather + compose belong to the timed region
     sync_all()
     elapsed = time.perf_counter() - t0
 
@@ -187,7 +216,10 @@ def main():
     value = total_px / elapsed / 1e6
 
     # per-pass device times on this rank (ms), from the events recorded inside the timed region
+    # (tiled runs record the events in the order luts, -, lights, composite: see frame())
     names = ["lights", "transmittance", "skyview", "composite", "gather+compose"]
+    if tiled:
+        names = ["transmittance+skyview_rows", "-", "lights(+lut allgather)", "composite", "compose(k-1)+gather start"]
     per = {n: float(np.mean([ev[k][i].elapsed_time(ev[k][i + 1]) for k in range(args.steps)])) for i, n in enumerate(names)}
     G_frame = int(g.item()) if tiled else geometry_px_local
     N_local = W * rows
@@ -213,6 +245,10 @@ def main():
             pass
     frame_bytes = bytes_composite + bytes_lights + bytes_luts
     frame_s = sum(per[n] for n in names[:4]) / 1e3
+    if tiled:
+        per.setdefault("lights", per[names[2]])
+        per.setdefault("transmittance", 0.0)
+        per.setdefault("skyview", per[names[0]])
 
     out = {
         "metric": "Mpixels/s deferred-lit+atmosphere", "value": value, "unit": "Mpixels/s", "n_gpus": args.gpus,
@@ -227,7 +263,7 @@ def main():
                            "achieved_GBps": frame_bytes / frame_s / 1e9, "frac": frame_bytes / frame_s / 1e9 / HBM_PEAK_GBS},
     }
 
-    if world == 1:
+    if world == 1 and not tiled:
         # The pass right after the path, measured on its own outside the timed region: in-place
         # OETF of the final image, 16 B/px. Not part of `value`.
         reps = 20
@@ -244,7 +280,7 @@ def main():
                             "achieved_GBps": 16 * W * H / (oetf_ms / 1e3) / 1e9,
                             "frac_of_8TBps": 16 * W * H / (oetf_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "in_value": False}
 
-    if world == 1:
+    if world == 1 and not tiled:
         # Extension without a reference counterpart (abi.h "Aerial-perspective froxel LUT"): APPROXIMATE composite that
         # replaces the inline per-pixel march by a froxel-LUT fetch. Reported separately, never part of `value`.
         reps = 10
@@ -270,7 +306,7 @@ def main():
     if rank == 0:
         log("per-pass device ms:", {k: round(v, 4) for k, v in per.items()})
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     deferred.cleanup()

@@ -50,19 +50,20 @@ def global_rows(height, rank, nranks, block_rows=DEFAULT_BLOCK_ROWS):
     return np.concatenate(out) if out else np.zeros((0,), np.int64)
 
 
-def gather_tiles(local_color, rank, nranks, gathered=None, dst=0, group=None):
+def gather_tiles(local_color, rank, nranks, gathered=None, dst=0, group=None, async_op=False):
     """The one collective of the path. `local_color`: [stride_rows, W, 4] int16 (RGBA16 UNORM bits)
     on every rank; `gathered`: [nranks, stride_rows, W, 4] on `dst` (allocated if None). Returns
-    `gathered` on dst, None elsewhere."""
+    `gathered` on dst, None elsewhere; with async_op=True returns (gathered_or_None, work) and the caller
+    must work.wait() before touching `gathered` or overwriting `local_color`."""
     # RCCL and gloo have no 16-bit integer type: move the tiles as bytes
     send = local_color.contiguous().view(torch.uint8)
     if rank == dst:
         if gathered is None:
             gathered = torch.empty((nranks,) + tuple(local_color.shape), dtype=local_color.dtype, device=local_color.device)
-        dist.gather(send, list(gathered.view(torch.uint8).unbind(0)), dst=dst, group=group)
-        return gathered
-    dist.gather(send, None, dst=dst, group=group)
-    return None
+        work = dist.gather(send, list(gathered.view(torch.uint8).unbind(0)), dst=dst, group=group, async_op=async_op)
+        return (gathered, work) if async_op else gathered
+    work = dist.gather(send, None, dst=dst, group=group, async_op=async_op)
+    return (None, work) if async_op else None
 
 
 def compose(gathered, height, nranks, block_rows=DEFAULT_BLOCK_ROWS, out=None, stream=None):
@@ -89,10 +90,11 @@ def lut_rows(height, rank, nranks):
     return rank * n, (rank + 1) * n
 
 
-def allgather_lut(lut, rank, nranks, group=None):
+def allgather_lut(lut, rank, nranks, group=None, async_op=False, force=False):
     """Second (optional) collective: every rank has filled rows lut_rows(...) of `lut` ([H, W, 4] float32,
-    the same buffer on every rank); exchange the slices in place so that every rank holds the whole LUT."""
-    if nranks <= 1:
-        return
+    the same buffer on every rank); exchange the slices in place so that every rank holds the whole LUT.
+    Returns the work handle when async_op=True (wait() before reading the LUT)."""
+    if nranks <= 1 and not force:
+        return None
     b, e = lut_rows(lut.shape[0], rank, nranks)
-    dist.all_gather_into_tensor(lut.view(-1), lut[b:e].reshape(-1).clone(), group=group)
+    return dist.all_gather_into_tensor(lut.view(-1), lut[b:e].reshape(-1).clone(), group=group, async_op=async_op)

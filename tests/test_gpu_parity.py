@@ -616,6 +616,48 @@ def test_oetf_known_values(gpu):
     assert out[0, 3, 0] == round(12.92 * 100)  # linear segment below the cutoff
 
 
+def test_rowtile_collectives_on_rccl_single_rank(gpu):
+    """The two collectives of the multi-GPU path through RCCL itself (a 1-rank group is all one GPU allows): byte
+    view gather of int16 tiles, in-place all-gather on the LUT memory the C library owns, async handles."""
+    import os
+
+    import torch.distributed as dist
+
+    from syzygy_amd import rowtile
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        tile = torch.randint(-32768, 32767, (16, 24, 4), dtype=torch.int16, device="cuda")
+        gathered, work = rowtile.gather_tiles(tile, 0, 1, async_op=True)
+        work.wait()
+        torch.cuda.synchronize()
+        assert gathered.shape == (1, 16, 24, 4) and torch.equal(gathered[0], tile)
+        out = rowtile.compose(gathered, 16, 1, 8)
+        torch.cuda.synchronize()
+        assert torch.equal(out, tile)
+
+        inp = util.Inputs(64, 64)
+        cameras, atmospheres, lights = staged(gpu, inp)
+        sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(128, 32), skyview_extent=(128, 64))
+        sky.recordTransmittance(None, 0, atmospheres)
+        sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+        torch.cuda.synchronize()
+        full = sky.download_lut(sky.skyviewLUT())
+        lut = sky.skyviewLUT_tensor()
+        lut.zero_()
+        b, e = rowtile.lut_rows(64, 0, 1)
+        sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, b, e)
+        work = rowtile.allgather_lut(lut, 0, 1, async_op=True, force=True)
+        work.wait()
+        torch.cuda.synchronize()
+        assert (sky.download_lut(sky.skyviewLUT()).view(np.uint32) == full.view(np.uint32)).all()
+        sky.destroy()
+    finally:
+        dist.destroy_process_group()
+
+
 def test_empty_draw_rect_is_a_no_op(gpu):
     inp = util.Inputs(32, 32, spots=1)
     cameras, atmospheres, lights = staged(gpu, inp)
