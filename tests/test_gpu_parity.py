@@ -658,6 +658,43 @@ def test_rowtile_collectives_on_rccl_single_rank(gpu):
         dist.destroy_process_group()
 
 
+def test_8k_row_tile_matches_oracle(gpu):
+    """7680x4320 (BASELINE config 4): one rank's cyclic row tile (rank 5 of 8, 8-row blocks) rendered on the GPU;
+    the oracle renders a 24-row band of the SAME frame through the contiguous-band tiling and the rows both
+    hold must agree to +-1 LSB (they are bit-identical today)."""
+    W, H = 7680, 4320
+    inp = util.Inputs(W, H, elevation_degrees=35.0, spots=64)
+    tile = util.rowtile(H, 8, 5, 8)
+    assert tile.local_rows == 536  # 540 blocks of 8 rows over 8 ranks: ranks 0-3 hold 68 blocks, ranks 4-7 hold 67
+    dbg, q = render_gpu(gpu, inp, tile=tile, lut=((512, 128), (2048, 1024)), debug=False)
+    assert q.shape == (536, W, 4) and (q[..., 3] == 65535).all()
+    gpu_rows = util.global_rows(H, 8, 5, 8)
+
+    band = 24
+    nbands = H // band
+    b = int(0.47 * nbands)
+    otile = util.rowtile(H, band, b, nbands)
+    frame = gpu.ob.HostFrame(W, band)
+    gpu.ob.gbuffer_fill(frame, inp.rect, otile, inp.cam, inp.synthetic.fill, threads=16)
+    gpu.ob.lights(frame, inp.rect, otile, None, inp.cam, inp.dirs, 2, 1, inp.spots, 64, threads=16)
+    tlut = gpu.ob.transmittance_lut(inp.atm, 512, 128, threads=16)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    skyp = gpu.pl.SkyViewComputePipeline.create()
+    skyp.upload_lut(skyp.transmittanceLUT(), tlut)
+    skyp.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)  # GPU sky-view LUT for both sides (parity-tested separately)
+    torch.cuda.synchronize()
+    slut = skyp.download_lut(skyp.skyviewLUT())
+    skyp.destroy()
+    gpu.ob.composite(frame, inp.rect, otile, None, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=16)
+    oracle_rows = util.global_rows(H, band, b, nbands)
+    common = np.intersect1d(gpu_rows, oracle_rows)
+    assert len(common) >= 8
+    gi = np.searchsorted(gpu_rows, common)
+    oi = np.searchsorted(oracle_rows, common)
+    lsb = np.abs(q[gi].astype(np.int32) - frame.color[oi].astype(np.int32))
+    assert lsb.max() <= 1, lsb.max()
+
+
 def test_empty_draw_rect_is_a_no_op(gpu):
     inp = util.Inputs(32, 32, spots=1)
     cameras, atmospheres, lights = staged(gpu, inp)
