@@ -98,6 +98,8 @@ void szg_projection_ortho_vk(const float min[3], const float max[3], szg_mat4* o
 /* geometryhelpers.cpp:147-157 */
 void szg_transform_vk(const float position[3], const float eulers[3], szg_mat4* out);
 void szg_view_vk(const float position[3], const float eulers[3], szg_mat4* out);
+/* geometry/transform.cpp:11-15 Transform::toMatrix (model matrix of a mesh instance, scene.cpp:205-211) */
+void szg_transform_matrix(const float translation[3], const float eulers[3], const float scale[3], szg_mat4* out);
 /* geometryhelpers.cpp:171-204 */
 void szg_projection_ortho_aabb_vk(const szg_mat4* view, const szg_aabb* bounds, szg_mat4* out);
 /* glm::inverse / glm::inverseTranspose / operator* on mat4 */

@@ -48,6 +48,9 @@ def _load(name):
         h.oracle_gbuffer_fill.argtypes = [P(abi.SceneTexture), abi.Rect, P(abi.RowTile), P(abi.GBuffer), P(abi.CameraPacked),
                                           U32, P(abi.FillScene), C.c_int]
         h.oracle_shadow_map.argtypes = [P(abi.Mat4), P(abi.Mat4), U32, P(abi.FillScene), FP, C.c_int]
+        h.oracle_gbuffer_raster.argtypes = [P(abi.SceneTexture), abi.Rect, P(abi.RowTile), P(abi.GBuffer), P(abi.CameraPacked), U32,
+                                            P(abi.MeshInstanced), U32, C.c_int]
+        h.oracle_shadow_raster.argtypes = [P(abi.Image), P(abi.Mat4), C.c_float, C.c_float, P(abi.MeshInstanced), U32, C.c_int]
         h.oracle_multiscatter_lut.argtypes = [P(abi.AtmospherePacked), U32, FP, U32, U32, U32, FP, FP]
         h.oracle_aerial_lut.argtypes = [P(abi.AtmospherePacked), U32, P(abi.CameraPacked), U32, FP, U32, U32, U32, U32, U32,
                                         C.c_float, FP, FP, C.c_int]
@@ -170,6 +173,27 @@ def gbuffer_fill(frame, draw_rect, tile, cam_packed, fill_scene, threads=1):
     g, st = frame.gbuffer(), frame.scene()
     lib().oracle_gbuffer_fill(C.byref(st), draw_rect, C.byref(tile) if tile is not None else None, C.byref(g),
                               C.byref(cam_packed), 0, C.byref(fill_scene), threads)
+
+
+def gbuffer_raster(frame, draw_rect, tile, cam_packed, meshes, threads=1):
+    """oracle_gbuffer_raster over syzygy_amd.meshes.MeshInstanced objects (host pointers)."""
+    from syzygy_amd.meshes import mesh_array
+
+    g, st = frame.gbuffer(), frame.scene()
+    arr = mesh_array(meshes, None)
+    lib().oracle_gbuffer_raster(C.byref(st), draw_rect, C.byref(tile) if tile is not None else None, C.byref(g),
+                                C.byref(cam_packed), 0, arr, len(meshes), threads)
+
+
+def shadow_raster(proj_view, dim, meshes, bias_constant=0.0, bias_slope=0.0, threads=1):
+    """One depth-only shadow raster of `meshes` with the light matrix `proj_view` (abi.Mat4)."""
+    from syzygy_amd.meshes import mesh_array
+
+    out = np.zeros((dim, dim), np.float32)
+    im = host_image(out, abi.SZG_FORMAT_D32_SFLOAT)
+    arr = mesh_array(meshes, None)
+    lib().oracle_shadow_raster(C.byref(im), C.byref(proj_view), float(bias_constant), float(bias_slope), arr, len(meshes), threads)
+    return out
 
 
 def lights(frame, draw_rect, tile, shadow_maps, cam_packed, dir_lights, dir_count, dir_skip, spot_lights, spot_count, threads=1):

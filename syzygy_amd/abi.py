@@ -193,6 +193,61 @@ class DeferredConfiguration(C.Structure):
     _fields_ = [("depthBiasConstant", C.c_float), ("depthBiasSlope", C.c_float)]
 
 
+# ---- szg/raster.h ---------------------------------------------------------
+class VertexPacked(C.Structure):
+    """renderer/gputypes.hpp:117-126"""
+
+    _fields_ = [
+        ("position", C.c_float * 3),
+        ("uv_x", C.c_float),
+        ("normal", C.c_float * 3),
+        ("uv_y", C.c_float),
+        ("color", C.c_float * 4),
+    ]
+
+
+class Texture(C.Structure):
+    _fields_ = [
+        ("data", C.c_void_p),
+        ("width", C.c_uint32),
+        ("height", C.c_uint32),
+        ("pitch_bytes", C.c_uint32),
+        ("srgb", C.c_uint32),
+    ]
+
+
+class Material(C.Structure):
+    _fields_ = [("color", Texture), ("normal", Texture), ("orm", Texture)]
+
+
+class Surface(C.Structure):
+    _fields_ = [("first_index", C.c_uint32), ("index_count", C.c_uint32), ("material", Material)]
+
+
+class MeshInstanced(C.Structure):
+    _fields_ = [
+        ("d_vertices", C.c_void_p),
+        ("vertex_count", C.c_uint32),
+        ("index_count", C.c_uint32),
+        ("d_indices", C.c_void_p),
+        ("surfaces", C.POINTER(Surface)),
+        ("surface_count", C.c_uint32),
+        ("instance_count", C.c_uint32),
+        ("d_models", C.c_void_p),
+        ("d_model_inverse_transposes", C.c_void_p),
+        ("render", C.c_uint32),
+        ("casts_shadow", C.c_uint32),
+    ]
+
+
+assert C.sizeof(VertexPacked) == 48
+
+VERTEX_DTYPE = np.dtype(
+    [("position", np.float32, 3), ("uv_x", np.float32), ("normal", np.float32, 3), ("uv_y", np.float32), ("color", np.float32, 4)]
+)
+assert VERTEX_DTYPE.itemsize == 48
+
+
 # ---- szg/host.h -----------------------------------------------------------
 class AABB(C.Structure):
     _fields_ = [("center", C.c_float * 3), ("half_extent", C.c_float * 3)]
@@ -308,6 +363,12 @@ ABI_FUNCTIONS = {
         [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, U32, P(SpotLightPacked), U32, U32, VP],
     ),
     "szg_deferred_record_shadow_maps": (C.c_int, [VP, VP, VP, U32, P(SpotLightPacked), U32, P(FillScene)]),
+    "szg_deferred_record_gbuffer_raster": (C.c_int, [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, P(MeshInstanced), U32]),
+    "szg_deferred_record_shadow_raster": (C.c_int, [VP, VP, VP, U32, P(SpotLightPacked), U32, P(MeshInstanced), U32]),
+    "szg_deferred_record_draw_commands_meshes": (
+        C.c_int,
+        [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, U32, P(SpotLightPacked), U32, U32, VP, P(MeshInstanced), U32],
+    ),
     "szg_deferred_gbuffer": (P(GBuffer), [VP]),
     "szg_deferred_shadow_maps": (P(ShadowMaps), [VP]),
     "szg_deferred_set_shadow_map": (C.c_int, [VP, U32, P(Image)]),
@@ -325,6 +386,7 @@ HOST_FUNCTIONS = {
     "szg_projection_ortho_vk": (None, [P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_transform_vk": (None, [P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_view_vk": (None, [P(C.c_float), P(C.c_float), P(Mat4)]),
+    "szg_transform_matrix": (None, [P(C.c_float), P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_projection_ortho_aabb_vk": (None, [P(Mat4), P(AABB), P(Mat4)]),
     "szg_mat4_inverse": (None, [P(Mat4), P(Mat4)]),
     "szg_mat4_inverse_transpose": (None, [P(Mat4), P(Mat4)]),

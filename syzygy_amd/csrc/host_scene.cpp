@@ -341,6 +341,16 @@ void szg_projection_vk(float fov_y_degrees, float aspect, float near_plane, floa
 void szg_projection_ortho_vk(const float mn[3], const float mx[3], szg_mat4* out) { *out = projectionOrthoVk(v3(mn), v3(mx)); }
 void szg_transform_vk(const float position[3], const float eulers[3], szg_mat4* out) { *out = transformVk(v3(position), v3(eulers)); }
 void szg_view_vk(const float position[3], const float eulers[3], szg_mat4* out) { *out = viewVk(v3(position), v3(eulers)); }
+// geometry/transform.cpp:11-15 Transform::toMatrix: glm::translate(t) * glm::orientate4(eulers) * glm::scale(s)
+void szg_transform_matrix(const float translation[3], const float eulers[3], const float scale[3], szg_mat4* out)
+{
+    szg_mat4 sc = zero4();
+    at(sc, 0, 0) = scale[0];
+    at(sc, 1, 1) = scale[1];
+    at(sc, 2, 2) = scale[2];
+    at(sc, 3, 3) = 1.0f;
+    *out = mul(mul(translate(v3(translation)), orientate4(v3(eulers))), sc);
+}
 void szg_projection_ortho_aabb_vk(const szg_mat4* view, const szg_aabb* bounds, szg_mat4* out)
 {
     *out = projectionOrthoAABBVk(*view, *bounds);

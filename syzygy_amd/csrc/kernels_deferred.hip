@@ -701,6 +701,19 @@ hipError_t launch_shadow_maps(hipStream_t s, const szg_directional_light_packed*
     return hipGetLastError();
 }
 
+hipError_t launch_shadow_prep(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount,
+                              const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_ownedSlots,
+                              unsigned slotCount, ShadowGen* d_gen)
+{
+    if (slotCount == 0u)
+    {
+        return hipSuccess;
+    }
+    hipLaunchKernelGGL(k_shadow_prep, dim3((slotCount + 63u) / 64u), dim3(64), 0, s, d_dir, dirCount, d_spot, spotCount, d_ownedSlots,
+                       slotCount, d_gen);
+    return hipGetLastError();
+}
+
 hipError_t launch_oetf(hipStream_t s, const szg_image& image, unsigned width, unsigned height, unsigned function)
 {
     if (width == 0u || height == 0u)

@@ -273,6 +273,13 @@ struct szg_deferred
     unsigned maxBoxes = 1024;
     unsigned maxDirectional = 16;
     StagingRing staging;
+    // compute rasteriser (szg/raster.h): buffers grow on demand and are kept
+    szg::RasterDraw* d_rasterDraws = nullptr;
+    size_t rasterDrawCapacity = 0;
+    szg::PrimRec* d_prims = nullptr;
+    uint2* d_primBoxes = nullptr;
+    uint2* d_chunkBoxes = nullptr;
+    size_t primCapacity = 0;
 };
 
 extern "C" {
@@ -773,7 +780,8 @@ void szg_deferred_destroy(szg_deferred_t* p)
             (void)hipFree(plane);
         }
     }
-    void* const rest[] = {p->d_ownedShadowMaps, p->d_spots, p->d_slots, p->d_lightRecs, p->d_boxes, p->d_ownedSlots, p->d_shadowGen};
+    void* const rest[] = {p->d_ownedShadowMaps, p->d_spots,       p->d_slots, p->d_lightRecs,  p->d_boxes,     p->d_ownedSlots,
+                          p->d_shadowGen,       p->d_rasterDraws, p->d_prims, p->d_primBoxes,  p->d_chunkBoxes};
     for (void* r : rest)
     {
         if (r != nullptr)
@@ -1087,4 +1095,277 @@ int szg_compose_rowtiles(void* stream, const void* gathered, size_t tile_stride_
     return SZG_OK;
 }
 
+// ---------------------------------------------------------------------------
+// Compute rasteriser (szg/raster.h)
+// ---------------------------------------------------------------------------
 } // extern "C"
+
+namespace
+{
+// Flatten the rendered meshes into the reference's draw calls (deferred.cpp:624-699 / pipelines.cpp:738-800):
+// one draw per (mesh, surface), primitives numbered instance-major.
+int collect_draws(const char* who, const szg_mesh_instanced* meshes, uint32_t meshCount, bool shadow,
+                  std::vector<szg::RasterDraw>& draws, uint32_t& primCount)
+{
+    draws.clear();
+    uint64_t prims = 0;
+    for (uint32_t i = 0; i < meshCount; i++)
+    {
+        szg_mesh_instanced const& m = meshes[i];
+        // collectGeometryCullFlags (deferred.cpp:394-428): render flag, mesh and both model buffers present
+        if (m.render == 0u || m.d_vertices == nullptr || m.d_indices == nullptr || m.d_models == nullptr ||
+            m.d_model_inverse_transposes == nullptr || m.instance_count == 0u)
+        {
+            continue;
+        }
+        if (shadow && m.casts_shadow == 0u) // pipelines.cpp:742
+        {
+            continue;
+        }
+        if (m.surface_count > 0u && m.surfaces == nullptr)
+        {
+            return fail(SZG_ERR_INVALID_ARGUMENT, "%s: mesh %u has %u surfaces but a NULL surface array", who, i, m.surface_count);
+        }
+        for (uint32_t k = 0; k < m.surface_count; k++)
+        {
+            szg_surface const& surf = m.surfaces[k];
+            uint32_t const avail = surf.first_index >= m.index_count ? 0u : m.index_count - surf.first_index;
+            uint32_t const tris = (surf.index_count < avail ? surf.index_count : avail) / 3u;
+            if (tris == 0u)
+            {
+                continue;
+            }
+            szg::RasterDraw d{};
+            d.vertices = m.d_vertices;
+            d.indices = m.d_indices;
+            d.models = m.d_models;
+            d.mits = m.d_model_inverse_transposes;
+            d.vertexCount = m.vertex_count;
+            d.firstIndex = surf.first_index;
+            d.triCount = tris;
+            d.instanceCount = m.instance_count;
+            d.firstPrim = (uint32_t)prims;
+            d.tex[0] = surf.material.color;
+            d.tex[1] = surf.material.normal;
+            d.tex[2] = surf.material.orm;
+            for (szg_texture const& t : d.tex)
+            {
+                if (t.data != nullptr && (t.width == 0u || t.height == 0u || t.width > 32768u || t.height > 32768u ||
+                                          t.pitch_bytes < t.width * 4u || t.pitch_bytes % 4u != 0u))
+                {
+                    return fail(SZG_ERR_INVALID_ARGUMENT, "%s: mesh %u surface %u has a malformed texture", who, i, k);
+                }
+            }
+            prims += (uint64_t)tris * m.instance_count;
+            if (prims > 0x40000000ull)
+            {
+                return fail(SZG_ERR_CAPACITY, "%s: more than 2^30 primitives", who);
+            }
+            draws.push_back(d);
+        }
+    }
+    primCount = (uint32_t)prims;
+    return SZG_OK;
+}
+
+int ensure_raster_capacity(szg_deferred* p, hipStream_t s, size_t draws, size_t prims)
+{
+    if (draws > p->rasterDrawCapacity)
+    {
+        SZG_HIP(hipStreamSynchronize(s));
+        if (p->d_rasterDraws != nullptr)
+        {
+            (void)hipFree(p->d_rasterDraws);
+            p->d_rasterDraws = nullptr;
+        }
+        size_t const n = draws * 2u;
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_rasterDraws), n * sizeof(szg::RasterDraw)));
+        p->rasterDrawCapacity = n;
+    }
+    if (prims > p->primCapacity)
+    {
+        SZG_HIP(hipStreamSynchronize(s));
+        void* const old[] = {p->d_prims, p->d_primBoxes, p->d_chunkBoxes};
+        for (void* o : old)
+        {
+            if (o != nullptr)
+            {
+                (void)hipFree(o);
+            }
+        }
+        p->d_prims = nullptr;
+        p->d_primBoxes = nullptr;
+        p->d_chunkBoxes = nullptr;
+        p->primCapacity = 0;
+        size_t const n = ((prims * 3u / 2u) + 63u) / 64u * 64u;
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_prims), n * sizeof(szg::PrimRec)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_primBoxes), n * sizeof(uint2)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_chunkBoxes), (n / 64u) * sizeof(uint2)));
+        p->primCapacity = n;
+    }
+    return SZG_OK;
+}
+
+int upload_draws(szg_deferred* p, hipStream_t s, const std::vector<szg::RasterDraw>& draws)
+{
+    size_t const per = p->staging.bytes / sizeof(szg::RasterDraw);
+    if (per == 0u)
+    {
+        return fail(SZG_ERR_CAPACITY, "staging ring smaller than one draw record");
+    }
+    for (size_t i = 0; i < draws.size(); i += per)
+    {
+        size_t const n = draws.size() - i < per ? draws.size() - i : per;
+        int const rc = p->staging.upload(s, p->d_rasterDraws + i, draws.data() + i, n * sizeof(szg::RasterDraw));
+        if (rc != SZG_OK)
+        {
+            return rc;
+        }
+    }
+    return SZG_OK;
+}
+} // namespace
+
+extern "C" {
+
+int szg_deferred_record_gbuffer_raster(szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
+                                       const szg_scene_texture* scene_texture, uint32_t view_camera_index,
+                                       const szg_camera_packed* d_cameras, const szg_mesh_instanced* meshes, uint32_t mesh_count)
+{
+    if (p == nullptr || d_cameras == nullptr || scene_texture == nullptr || (mesh_count > 0u && meshes == nullptr))
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_gbuffer_raster: NULL argument");
+    }
+    if (draw_rect.width == 0u || draw_rect.height == 0u)
+    {
+        return SZG_OK;
+    }
+    if (draw_rect.width > 32768u || draw_rect.height > 32768u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_gbuffer_raster: draw extent above 32768");
+    }
+    szg::TileArgs t{};
+    if (!resolve_tile(tile, draw_rect.height, t))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    if (!check_gbuffer(&p->gbuffer, draw_rect.width, t.local_rows) ||
+        !check_image(scene_texture->depth, SZG_FORMAT_D32_SFLOAT, draw_rect.width, t.local_rows, "scene_texture.depth"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    std::vector<szg::RasterDraw> draws;
+    uint32_t primCount = 0;
+    int rc = collect_draws("szg_deferred_record_gbuffer_raster", meshes, mesh_count, false, draws, primCount);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    rc = ensure_raster_capacity(p, s, draws.size(), primCount);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    rc = upload_draws(p, s, draws);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    SZG_HIP(szg::launch_raster_setup(s, false, p->d_rasterDraws, (unsigned)draws.size(), primCount, d_cameras, view_camera_index, nullptr,
+                                     draw_rect.width, draw_rect.height, p->d_prims, p->d_primBoxes, p->d_chunkBoxes));
+    SZG_HIP(szg::launch_raster_tile(s, *scene_texture, draw_rect.width, draw_rect.height, t, p->gbuffer, p->d_rasterDraws, p->d_prims,
+                                    p->d_primBoxes, p->d_chunkBoxes, primCount, d_cameras, view_camera_index));
+    return SZG_OK;
+}
+
+int szg_deferred_record_shadow_raster(szg_deferred_t* p, void* stream, const szg_directional_light_packed* d_directional_lights,
+                                      uint32_t directional_light_count, const szg_spot_light_packed* h_spot_lights,
+                                      uint32_t spot_light_count, const szg_mesh_instanced* meshes, uint32_t mesh_count)
+{
+    if (p == nullptr || (mesh_count > 0u && meshes == nullptr))
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_shadow_raster: NULL argument");
+    }
+    if ((directional_light_count > 0u && d_directional_lights == nullptr) || (spot_light_count > 0u && h_spot_lights == nullptr))
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_shadow_raster: light array NULL");
+    }
+    if (spot_light_count > p->desc.max_spot_lights)
+    {
+        return fail(SZG_ERR_CAPACITY, "szg_deferred_record_shadow_raster: %u spot lights exceed the capacity %u", spot_light_count,
+                    p->desc.max_spot_lights);
+    }
+    if (p->d_ownedShadowMaps == nullptr)
+    {
+        return SZG_OK; // the pipeline owns no shadow maps
+    }
+    unsigned const lights = directional_light_count + spot_light_count;
+    unsigned const slots = lights < p->desc.max_shadow_maps ? lights : p->desc.max_shadow_maps; // shadowpass.cpp:219-225
+    if (slots == 0u)
+    {
+        return SZG_OK;
+    }
+    std::vector<szg::RasterDraw> draws;
+    uint32_t primCount = 0;
+    int rc = collect_draws("szg_deferred_record_shadow_raster", meshes, mesh_count, true, draws, primCount);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    rc = ensure_raster_capacity(p, s, draws.size(), primCount);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    rc = p->staging.upload(s, p->d_spots, h_spot_lights, (size_t)spot_light_count * sizeof(szg_spot_light_packed));
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    rc = upload_draws(p, s, draws);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    SZG_HIP(szg::launch_shadow_prep(s, d_directional_lights, directional_light_count, p->d_spots, spot_light_count, p->d_ownedSlots, slots,
+                                    p->d_shadowGen));
+    unsigned const dim = p->desc.shadow_map_dim;
+    for (unsigned slot = 0; slot < slots; slot++)
+    {
+        // the primitive buffers are reused slot after slot: stream order keeps setup(k+1) behind tile(k)
+        SZG_HIP(szg::launch_raster_setup(s, true, p->d_rasterDraws, (unsigned)draws.size(), primCount, nullptr, 0u, p->d_shadowGen + slot, dim,
+                                         dim, p->d_prims, p->d_primBoxes, p->d_chunkBoxes));
+        SZG_HIP(szg::launch_shadow_tile(s, p->d_shadowGen + slot, dim, p->d_prims, p->d_primBoxes, p->d_chunkBoxes, primCount,
+                                        p->config.depthBiasConstant, p->config.depthBiasSlope));
+    }
+    return SZG_OK;
+}
+
+int szg_deferred_record_draw_commands_meshes(szg_deferred_t* p, void* stream, szg_rect draw_rect, const szg_rowtile* tile,
+                                             const szg_scene_texture* scene_texture, uint32_t atmospheric_directional_lights_count,
+                                             const szg_directional_light_packed* d_directional_lights,
+                                             uint32_t directional_light_count, const szg_spot_light_packed* h_spot_lights,
+                                             uint32_t spot_light_count, uint32_t view_camera_index, const szg_camera_packed* d_cameras,
+                                             const szg_mesh_instanced* meshes, uint32_t mesh_count)
+{
+    // deferred.cpp:480-490 shadow maps, :493-713 G-buffer pass, :715-787 lights
+    int rc = szg_deferred_record_shadow_raster(p, stream, d_directional_lights, directional_light_count, h_spot_lights, spot_light_count,
+                                               meshes, mesh_count);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    rc = szg_deferred_record_gbuffer_raster(p, stream, draw_rect, tile, scene_texture, view_camera_index, d_cameras, meshes, mesh_count);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    return szg_deferred_record_lights(p, stream, draw_rect, tile, scene_texture, atmospheric_directional_lights_count,
+                                      d_directional_lights, directional_light_count, h_spot_lights, spot_light_count, view_camera_index,
+                                      d_cameras);
+}
+
+} // extern "C"
+

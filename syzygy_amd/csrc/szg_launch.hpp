@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "szg/abi.h"
+#include "szg/raster.h"
 
 namespace szg
 {
@@ -82,6 +83,40 @@ struct ShadowGen
 hipError_t launch_shadow_maps(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount,
                               const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_ownedSlots,
                               unsigned slotCount, ShadowGen* d_gen, const szg_fill_box* d_boxes, unsigned boxCount, unsigned maxDim);
+hipError_t launch_shadow_prep(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount,
+                              const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_ownedSlots,
+                              unsigned slotCount, ShadowGen* d_gen);
+
+// ---- compute rasteriser (kernels_raster.hip, include/szg/raster.h) ----
+// One vkCmdDrawIndexed of the reference (one surface of one mesh, all its instances), uploaded by the host.
+struct RasterDraw
+{
+    const szg_vertex_packed* vertices;
+    const uint32_t* indices;
+    const szg_mat4* models;
+    const szg_mat4* mits;
+    uint32_t vertexCount, firstIndex, triCount, instanceCount;
+    uint32_t firstPrim; // submission-order number of this draw's first primitive (instance-major, then triangle)
+    uint32_t pad;
+    szg_texture tex[3]; // color, normal, ORM (offscreen.frag:19-21)
+};
+// One assembled primitive: signed homogeneous edge functions + clip z, w per vertex (raster.h "coverage", "depth").
+struct PrimRec
+{
+    float a[3], b[3], c[3];
+    float z[3], w[3];
+    uint32_t draw, instance, tri;
+    uint32_t pad[2];
+};
+static_assert(sizeof(PrimRec) == 80, "PrimRec layout");
+hipError_t launch_raster_setup(hipStream_t s, bool shadow, const RasterDraw* d_draws, unsigned drawCount, unsigned primCount,
+                               const szg_camera_packed* d_cam, unsigned camIndex, const ShadowGen* d_gen, unsigned W, unsigned H,
+                               PrimRec* d_prims, uint2* d_boxes, uint2* d_chunkBoxes);
+hipError_t launch_raster_tile(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
+                              const szg_gbuffer& g, const RasterDraw* d_draws, const PrimRec* d_prims, const uint2* d_boxes,
+                              const uint2* d_chunkBoxes, unsigned primCount, const szg_camera_packed* d_cam, unsigned camIndex);
+hipError_t launch_shadow_tile(hipStream_t s, const ShadowGen* d_gen, unsigned dim, const PrimRec* d_prims, const uint2* d_boxes,
+                              const uint2* d_chunkBoxes, unsigned primCount, float biasConstant, float biasSlope);
 hipError_t launch_oetf(hipStream_t s, const szg_image& image, unsigned width, unsigned height, unsigned function);
 hipError_t launch_compose_rowtiles(hipStream_t s, const void* gathered, size_t tileStrideBytes, unsigned nranks,
                                    unsigned blockRows, const szg_image& dst, unsigned width, unsigned height);
