@@ -37,6 +37,7 @@ def lib():
         handle = ctypes.CDLL(path)
         abi.bind(handle, abi.ABI_FUNCTIONS)
         abi.bind(handle, abi.HOST_FUNCTIONS)
+        abi.bind(handle, abi.RASTER_FUNCTIONS)
         if handle.szg_abi_version() != abi.SZG_ABI_VERSION:
             raise RuntimeError("libszg_hip.so ABI version mismatch")
         _LIB = handle

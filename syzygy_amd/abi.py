@@ -363,12 +363,6 @@ ABI_FUNCTIONS = {
         [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, U32, P(SpotLightPacked), U32, U32, VP],
     ),
     "szg_deferred_record_shadow_maps": (C.c_int, [VP, VP, VP, U32, P(SpotLightPacked), U32, P(FillScene)]),
-    "szg_deferred_record_gbuffer_raster": (C.c_int, [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, P(MeshInstanced), U32]),
-    "szg_deferred_record_shadow_raster": (C.c_int, [VP, VP, VP, U32, P(SpotLightPacked), U32, P(MeshInstanced), U32]),
-    "szg_deferred_record_draw_commands_meshes": (
-        C.c_int,
-        [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, U32, P(SpotLightPacked), U32, U32, VP, P(MeshInstanced), U32],
-    ),
     "szg_deferred_gbuffer": (P(GBuffer), [VP]),
     "szg_deferred_shadow_maps": (P(ShadowMaps), [VP]),
     "szg_deferred_set_shadow_map": (C.c_int, [VP, U32, P(Image)]),
@@ -377,6 +371,16 @@ ABI_FUNCTIONS = {
     "szg_record_oetf": (C.c_int, [VP, P(Image), U32, U32, U32]),
     "szg_compose_rowtiles": (C.c_int, [VP, VP, C.c_size_t, U32, U32, P(Image), U32, U32]),
     "szg_rowtile_local_rows": (U32, [U32, U32, U32, U32]),
+}
+
+# include/szg/raster.h
+RASTER_FUNCTIONS = {
+    "szg_deferred_record_gbuffer_raster": (C.c_int, [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, P(MeshInstanced), U32]),
+    "szg_deferred_record_shadow_raster": (C.c_int, [VP, VP, VP, U32, P(SpotLightPacked), U32, P(MeshInstanced), U32]),
+    "szg_deferred_record_draw_commands_meshes": (
+        C.c_int,
+        [VP, VP, Rect, P(RowTile), P(SceneTexture), U32, VP, U32, P(SpotLightPacked), U32, U32, VP, P(MeshInstanced), U32],
+    ),
 }
 
 HOST_FUNCTIONS = {

@@ -1,5 +1,5 @@
 """The C-ABI library loads on a machine without a GPU, exports every symbol that
-include/szg/abi.h and include/szg/host.h declare, keeps the reference's struct sizes,
+include/szg/abi.h, include/szg/host.h and include/szg/raster.h declare, keeps the reference's struct sizes,
 and fails loudly (no CPU fallback) when asked to create a pipeline without a device."""
 import ctypes as C
 import os
@@ -23,7 +23,8 @@ def test_library_is_in_tree():
     assert library_path().startswith(ROOT)
 
 
-@pytest.mark.parametrize("header,table", [("abi.h", abi.ABI_FUNCTIONS), ("host.h", abi.HOST_FUNCTIONS)])
+@pytest.mark.parametrize("header,table", [("abi.h", abi.ABI_FUNCTIONS), ("host.h", abi.HOST_FUNCTIONS),
+                                          ("raster.h", abi.RASTER_FUNCTIONS)])
 def test_every_declared_symbol_is_exported_and_bound(header, table):
     handle = C.CDLL(library_path())
     names = declared_symbols(header)
@@ -41,6 +42,7 @@ def test_struct_sizes_match_the_reference():
     assert C.sizeof(abi.AtmospherePacked) == 128
     assert C.sizeof(abi.DirectionalLightPacked) == 176
     assert C.sizeof(abi.SpotLightPacked) == 192
+    assert C.sizeof(abi.VertexPacked) == 48  # gputypes.hpp:126
     # std430 offsets used by the shaders (types/atmosphere.glinl)
     assert abi.AtmospherePacked.incidentDirectionSun.offset == 64
     assert abi.AtmospherePacked.sunIntensitySpectrum.offset == 112
