@@ -27,6 +27,7 @@
 #include <vector>
 
 #include "szg/abi.h"
+#include "szg/raster.h"
 #include "szg/host.h"
 
 namespace szg
@@ -215,6 +216,22 @@ struct DeferredShadingPipeline
                                                 static_cast<uint32_t>(directionalLights.deviceSize()), spotLights.data(),
                                                 static_cast<uint32_t>(spotLights.size()), viewCameraIndex,
                                                 cameras.deviceAddress(), sceneGeometry);
+    }
+    // deferred.hpp:34-44 with the reference's own last argument, std::span<MeshInstanced const> sceneGeometry
+    // (szg/raster.h): shadow raster, G-buffer raster, lights.
+    void recordDrawCommands(hipStream_t cmd, szg_rect drawRect, SceneTexture& sceneTexture,
+                            uint32_t atmosphericDirectionalLightsCount,
+                            TStagedBuffer<DirectionalLightPacked> const& directionalLights,
+                            std::span<SpotLightPacked const> spotLights, uint32_t viewCameraIndex,
+                            TStagedBuffer<CameraPacked> const& cameras, std::span<szg_mesh_instanced const> sceneGeometry,
+                            szg_rowtile const* tile = nullptr)
+    {
+        (void)szg_deferred_record_draw_commands_meshes(m_handle, cmd, drawRect, tile, &sceneTexture.texture(),
+                                                       atmosphericDirectionalLightsCount, directionalLights.deviceAddress(),
+                                                       static_cast<uint32_t>(directionalLights.deviceSize()), spotLights.data(),
+                                                       static_cast<uint32_t>(spotLights.size()), viewCameraIndex,
+                                                       cameras.deviceAddress(), sceneGeometry.data(),
+                                                       static_cast<uint32_t>(sceneGeometry.size()));
     }
     [[nodiscard]] auto gbuffer() -> szg_gbuffer const& { return *szg_deferred_gbuffer(m_handle); }          // deferred.hpp:46
     [[nodiscard]] auto shadowMaps() -> szg_shadowmaps const& { return *szg_deferred_shadow_maps(m_handle); } // deferred.hpp:47
