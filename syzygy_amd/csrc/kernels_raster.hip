@@ -2,13 +2,16 @@
 // DeferredShadingPipeline::recordDrawCommands (include/szg/raster.h states the rules and cites the reference).
 //
 //   k_raster_setup   one lane per primitive in submission order: vertex stage for its three vertices, homogeneous
-//                    edge functions, facing / trivial rejection, screen bounding box; one wave = one chunk of 64
-//                    primitives whose union box is reduced across the lanes
-//   k_raster_tile    256 threads = 32x8 pixels, each wave an 8x8 patch that walks the chunks: chunk box vs patch
-//                    (scalar), then 64 primitive boxes vs patch in parallel (one per lane, ballot), then the
-//                    surviving primitives one by one with wave-uniform coefficients (scalar loads) — depth test in
-//                    registers, no atomics; the winner is shaded (offscreen.frag) and all five planes + depth are
-//                    written once: 52 B/px, coalesced
+//                    edge functions, facing / trivial rejection, screen bounding box, and a sort key (box size class,
+//                    Morton code of the box centre)
+//   (rocPRIM radix sort of the keys when there are more than a few thousand primitives: kernels_raster_sort.hip)
+//   k_raster_chunks / k_raster_superchunks   box hierarchy over the (sorted) order: 64 primitives per chunk,
+//                    64 chunks per super-chunk, union boxes by wave reductions
+//   k_raster_tile    256 threads = 32x8 pixels, each wave an 8x8 patch that walks the hierarchy: super-chunk box vs
+//                    patch (scalar), 64 chunk boxes in parallel (one per lane, ballot), 64 primitive boxes in parallel,
+//                    then the surviving primitives one by one with wave-uniform coefficients (scalar loads) — depth
+//                    test in registers, no atomics; the winner is shaded (offscreen.frag) and all five planes + depth
+//                    are written once: 52 B/px, coalesced
 //   k_shadow_tile    the same walk, depth only (front faces culled, GREATER_OR_EQUAL, depth bias)
 
 #include "szg_device.hpp"
@@ -80,6 +83,16 @@ SZG_DEV VertexOut vertexStage(const RasterDraw& d, unsigned instance, unsigned i
 }
 
 SZG_DEV unsigned packBox(int lo, int hi) { return (unsigned)lo | ((unsigned)hi << 16); }
+SZG_DEV unsigned spread14(unsigned v) // 14 bits -> every other bit of 28
+{
+    v &= 0x3FFFu;
+    v = (v | (v << 8)) & 0x00FF00FFu;
+    v = (v | (v << 4)) & 0x0F0F0F0Fu;
+    v = (v | (v << 2)) & 0x33333333u;
+    v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+SZG_DEV unsigned morton14(unsigned x, unsigned y) { return spread14(x) | (spread14(y) << 1); }
 unsigned const EMPTY_BOX = 65535u | (0u << 16); // min 65535 > max 0: overlaps no patch
 
 SZG_DEV int waveMin(int v)
@@ -109,7 +122,7 @@ __global__ __launch_bounds__(64) void k_raster_setup(const RasterDraw* __restric
                                                      const szg_camera_packed* __restrict__ cameras, unsigned cameraIndex,
                                                      const ShadowGen* __restrict__ gen, unsigned W, unsigned H,
                                                      PrimRec* __restrict__ prims, uint2* __restrict__ boxes,
-                                                     uint2* __restrict__ chunkBoxes)
+                                                     unsigned* __restrict__ keys, unsigned* __restrict__ order)
 {
     unsigned const p = blockIdx.x * 64u + threadIdx.x;
     int minX = 65535, maxX = 0, minY = 65535, maxY = 0; // empty
@@ -229,14 +242,49 @@ __global__ __launch_bounds__(64) void k_raster_setup(const RasterDraw* __restric
         }
         prims[p] = r;
         boxes[p] = make_uint2(packBox(minX, maxX), packBox(minY, maxY));
+        // sort key: large boxes first (they would bloat every chunk they land in), then Morton order of the centre
+        unsigned key = 0xFFFFFFFFu; // culled primitives last
+        if (minX <= maxX)
+        {
+            unsigned const extent = (unsigned)max(maxX - minX, maxY - minY) + 1u;
+            unsigned const sizeClass = 15u - min(15u, 31u - (unsigned)__builtin_clz(extent)); // 0 = largest
+            key = (sizeClass << 28) | morton14((unsigned)(minX + maxX) >> 2, (unsigned)(minY + maxY) >> 2);
+        }
+        keys[p] = key;
+        order[p] = p;
     }
-    // union box of the chunk (empty lanes contribute nothing)
-    bool const has = minX <= maxX && minY <= maxY;
-    int const cx0 = waveMin(has ? minX : 65535), cx1 = waveMax(has ? maxX : -1);
-    int const cy0 = waveMin(has ? minY : 65535), cy1 = waveMax(has ? maxY : -1);
+}
+
+// Box hierarchy over `order` (submission order, or the sorted one): one wave per chunk of 64 primitives.
+__global__ __launch_bounds__(64) void k_raster_chunks(const unsigned* __restrict__ order, const uint2* __restrict__ boxes,
+                                                      unsigned primCount, uint2* __restrict__ orderedBoxes,
+                                                      uint2* __restrict__ chunkBoxes)
+{
+    unsigned const pos = blockIdx.x * 64u + threadIdx.x;
+    uint2 box = make_uint2(EMPTY_BOX, EMPTY_BOX);
+    if (pos < primCount)
+    {
+        box = boxes[order[pos]];
+        orderedBoxes[pos] = box;
+    }
+    int const x0 = waveMin((int)(box.x & 0xFFFFu)), x1 = waveMax((int)(box.x >> 16));
+    int const y0 = waveMin((int)(box.y & 0xFFFFu)), y1 = waveMax((int)(box.y >> 16));
     if (threadIdx.x == 0u)
     {
-        chunkBoxes[blockIdx.x] = (cx0 <= cx1) ? make_uint2(packBox(cx0, cx1), packBox(cy0, cy1)) : make_uint2(EMPTY_BOX, EMPTY_BOX);
+        chunkBoxes[blockIdx.x] = (x0 <= x1 && y0 <= y1) ? make_uint2(packBox(x0, x1), packBox(y0, y1)) : make_uint2(EMPTY_BOX, EMPTY_BOX);
+    }
+}
+// one wave per super-chunk of 64 chunks
+__global__ __launch_bounds__(64) void k_raster_superchunks(const uint2* __restrict__ chunkBoxes, unsigned chunkCount,
+                                                           uint2* __restrict__ superBoxes)
+{
+    unsigned const c = blockIdx.x * 64u + threadIdx.x;
+    uint2 const box = c < chunkCount ? chunkBoxes[c] : make_uint2(EMPTY_BOX, EMPTY_BOX);
+    int const x0 = waveMin((int)(box.x & 0xFFFFu)), x1 = waveMax((int)(box.x >> 16));
+    int const y0 = waveMin((int)(box.y & 0xFFFFu)), y1 = waveMax((int)(box.y >> 16));
+    if (threadIdx.x == 0u)
+    {
+        superBoxes[blockIdx.x] = (x0 <= x1 && y0 <= y1) ? make_uint2(packBox(x0, x1), packBox(y0, y1)) : make_uint2(EMPTY_BOX, EMPTY_BOX);
     }
 }
 
@@ -278,28 +326,41 @@ SZG_DEV bool fragmentDepth(const PrimRec* __restrict__ t, const float e[3], floa
     return ok;
 }
 
-// Walk of the chunk / primitive boxes for one 8x8 patch; `visit(primIndex)` is called with a wave-uniform index.
-template <typename F>
-SZG_DEV void walkPrimitives(const uint2* __restrict__ chunkBoxes, const uint2* __restrict__ boxes, unsigned primCount, int x0, int x1,
-                            int y0, int y1, F&& visit)
+// The box hierarchy a tile kernel walks (all in the order of `order`).
+struct Hierarchy
+{
+    const uint2* superBoxes;
+    const uint2* chunkBoxes;
+    const uint2* orderedBoxes;
+    const unsigned* order;
+    unsigned primCount;
+};
+// Walk for one 8x8 patch; `visit(primIndex)` is called with a wave-uniform submission-order index.
+template <typename F> SZG_DEV void walkPrimitives(const Hierarchy& h, int x0, int x1, int y0, int y1, F&& visit)
 {
     unsigned const lane = threadIdx.x & 63u;
-    unsigned const chunks = (primCount + 63u) / 64u;
-    for (unsigned c = 0; c < chunks; c++)
+    unsigned const chunks = (h.primCount + 63u) / 64u;
+    unsigned const supers = (chunks + 63u) / 64u;
+    for (unsigned sc = 0; sc < supers; sc++)
     {
-        uint2 const cb = chunkBoxes[c]; // uniform address: scalar load
-        if (!boxOverlaps(cb, x0, x1, y0, y1))
+        if (!boxOverlaps(h.superBoxes[sc], x0, x1, y0, y1)) // uniform address: scalar load
         {
             continue;
         }
-        unsigned const p = c * 64u + lane;
-        bool const candidate = p < primCount && boxOverlaps(boxes[p], x0, x1, y0, y1);
-        unsigned long long mask = __ballot(candidate);
-        while (mask != 0ull)
+        unsigned const c = sc * 64u + lane;
+        unsigned long long chunkMask = __ballot(c < chunks && boxOverlaps(h.chunkBoxes[c], x0, x1, y0, y1));
+        while (chunkMask != 0ull)
         {
-            unsigned const bit = (unsigned)__builtin_ctzll(mask);
-            mask &= mask - 1ull;
-            visit(c * 64u + bit);
+            unsigned const chunk = sc * 64u + (unsigned)__builtin_ctzll(chunkMask);
+            chunkMask &= chunkMask - 1ull;
+            unsigned const pos = chunk * 64u + lane;
+            unsigned long long mask = __ballot(pos < h.primCount && boxOverlaps(h.orderedBoxes[pos], x0, x1, y0, y1));
+            while (mask != 0ull)
+            {
+                unsigned const bit = (unsigned)__builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                visit(h.order[chunk * 64u + bit]);
+            }
         }
     }
 }
@@ -350,7 +411,9 @@ SZG_DEV int wrapIndex(float f, int n)
     }
     return i;
 }
-SZG_DEV V3 sampleTexture(const szg_texture& tex, V2 st)
+// `unormTable[b]` = decode8(b, false), `srgbTable[b]` = decode8(b, true): the 36 texel decodes of a pixel are LDS
+// look-ups of values each computed once per workgroup by the same expression.
+SZG_DEV V3 sampleTexture(const szg_texture& tex, V2 st, const float* unormTable, const float* srgbTable)
 {
     if (tex.data == nullptr || tex.width == 0u || tex.height == 0u)
     {
@@ -368,23 +431,24 @@ SZG_DEV V3 sampleTexture(const szg_texture& tex, V2 st)
     unsigned const t10 = *reinterpret_cast<const unsigned*>(base + (size_t)j0 * tex.pitch_bytes + (size_t)i1 * 4u);
     unsigned const t01 = *reinterpret_cast<const unsigned*>(base + (size_t)j1 * tex.pitch_bytes + (size_t)i0 * 4u);
     unsigned const t11 = *reinterpret_cast<const unsigned*>(base + (size_t)j1 * tex.pitch_bytes + (size_t)i1 * 4u);
-    bool const srgb = tex.srgb != 0u;
+    const float* const table = tex.srgb != 0u ? srgbTable : unormTable;
     float const w00 = (1.0f - a) * (1.0f - b), w10 = a * (1.0f - b), w01 = (1.0f - a) * b, w11 = a * b;
     float r[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ch++)
     {
         unsigned const sh = (unsigned)ch * 8u;
-        r[ch] = w00 * decode8((t00 >> sh) & 0xFFu, srgb) + w10 * decode8((t10 >> sh) & 0xFFu, srgb) +
-                w01 * decode8((t01 >> sh) & 0xFFu, srgb) + w11 * decode8((t11 >> sh) & 0xFFu, srgb);
+        r[ch] = w00 * table[(t00 >> sh) & 0xFFu] + w10 * table[(t10 >> sh) & 0xFFu] + w01 * table[(t01 >> sh) & 0xFFu] +
+                w11 * table[(t11 >> sh) & 0xFFu];
     }
     return mk3(r[0], r[1], r[2]);
 }
 
 // deferred/offscreen.frag:25-59
-SZG_DEV V3 perturbNormal(const szg_texture& normalMap, V3 N, V3 dPosDx, V3 dPosDy, V2 dUvDx, V2 dUvDy, V2 texcoord)
+SZG_DEV V3 perturbNormal(const szg_texture& normalMap, V3 N, V3 dPosDx, V3 dPosDy, V2 dUvDx, V2 dUvDy, V2 texcoord,
+                         const float* unormTable, const float* srgbTable)
 {
-    V3 map = sampleTexture(normalMap, texcoord);
+    V3 map = sampleTexture(normalMap, texcoord, unormTable, srgbTable);
     float const k = 128.0f / 127.0f;
     map = mk3(map.x * 255.0f / 127.0f - k, map.y * 255.0f / 127.0f - k, map.z * 255.0f / 127.0f - k); // :47
     map.y = -map.y;                                                                                    // :50
@@ -405,11 +469,16 @@ SZG_DEV V3 perturbNormal(const szg_texture& normalMap, V3 N, V3 dPosDx, V3 dPosD
 __global__ __launch_bounds__(256) void k_raster_tile(szg_image depth, szg_image gDiffuse, szg_image gSpecular, szg_image gNormal,
                                                      szg_image gPosition, szg_image gOrm, unsigned drawW, unsigned drawH,
                                                      unsigned localRows, RowMap rm, const RasterDraw* __restrict__ draws,
-                                                     const PrimRec* __restrict__ prims, const uint2* __restrict__ boxes,
-                                                     const uint2* __restrict__ chunkBoxes, unsigned primCount,
+                                                     const PrimRec* __restrict__ prims, Hierarchy hier,
                                                      const szg_camera_packed* __restrict__ cameras, unsigned cameraIndex)
 {
     unsigned const tid = threadIdx.x;
+    // RGBA8 decode tables (one entry per thread, both by the expression of decode8)
+    __shared__ float s_unorm[256];
+    __shared__ float s_srgb[256];
+    s_unorm[tid] = decode8(tid, false);
+    s_srgb[tid] = decode8(tid, true);
+    __syncthreads();
     unsigned const wave = tid >> 6, lane = tid & 63u;
     unsigned const patchX = blockIdx.x * 32u + wave * 8u;
     unsigned const patchY = blockIdx.y * 8u;
@@ -429,13 +498,14 @@ __global__ __launch_bounds__(256) void k_raster_tile(szg_image depth, szg_image 
     float const px = (float)x + 0.5f, py = (float)gy + 0.5f;
     float best = 0.0f; // cleared depth; compare GREATER (deferred.cpp:383-386)
     unsigned winner = 0xFFFFFFFFu;
-    walkPrimitives(chunkBoxes, boxes, primCount, x0, x1, y0, y1, [&](unsigned p) {
+    walkPrimitives(hier, x0, x1, y0, y1, [&](unsigned p) {
         const PrimRec* t = prims + p;
         float e[3];
         edgeFunctions(t, px, py, e);
         float d;
         bool const ok = fragmentDepth(t, e, d);
-        if (coversPixel(t, e) && ok && d > best)
+        // GREATER in submission order: the walk order is arbitrary, so an equal depth goes to the earlier primitive
+        if (coversPixel(t, e) && ok && (d > best || (d == best && p < winner)))
         {
             best = d;
             winner = p;
@@ -459,14 +529,17 @@ __global__ __launch_bounds__(256) void k_raster_tile(szg_image depth, szg_image 
         v[1] = vertexStage<false>(d, t.instance, d.indices[base + 1u], projView);
         v[2] = vertexStage<false>(d, t.instance, d.indices[base + 2u], projView);
         Varyings const in = interpolate(t, v, px, py);
-        // fine derivatives over the 2x2 quad (raster.h "derivatives")
-        float const qx = (float)(x & ~1u) + 0.5f, qy = (float)(gy & ~1u) + 0.5f;
-        Varyings const xl = interpolate(t, v, qx, py), xr = interpolate(t, v, qx + 1.0f, py);
-        Varyings const yt = interpolate(t, v, px, qy), yb = interpolate(t, v, px, qy + 1.0f);
+        // fine derivatives over the 2x2 quad (raster.h "derivatives"): right minus left, bottom minus top. One of the
+        // two pixels of each difference is this pixel itself, so only the other one is interpolated.
+        bool const isLeft = (x & 1u) == 0u, isTop = (gy & 1u) == 0u;
+        Varyings const ox = interpolate(t, v, isLeft ? px + 1.0f : px - 1.0f, py);
+        Varyings const oy = interpolate(t, v, px, isTop ? py + 1.0f : py - 1.0f);
+        Varyings const xl = isLeft ? in : ox, xr = isLeft ? ox : in;
+        Varyings const yt = isTop ? in : oy, yb = isTop ? oy : in;
         V2 const dUvDx{xr.uv.x - xl.uv.x, xr.uv.y - xl.uv.y}, dUvDy{yb.uv.x - yt.uv.x, yb.uv.y - yt.uv.y};
-        V3 const N = perturbNormal(d.tex[1], in.normal, xr.world - xl.world, yb.world - yt.world, dUvDx, dUvDy, in.uv);
-        V3 const color = sampleTexture(d.tex[0], in.uv);
-        V3 const o = sampleTexture(d.tex[2], in.uv);
+        V3 const N = perturbNormal(d.tex[1], in.normal, xr.world - xl.world, yb.world - yt.world, dUvDx, dUvDy, in.uv, s_unorm, s_srgb);
+        V3 const color = sampleTexture(d.tex[0], in.uv, s_unorm, s_srgb);
+        V3 const o = sampleTexture(d.tex[2], in.uv, s_unorm, s_srgb);
         dif = pack_half4(color.x, color.y, color.z, 1.0f);  // offscreen.frag:72, :75
         nrm = pack_half4(N.x, N.y, N.z, 0.0f);               // :68
         orm = pack_half4(o.x, o.y, o.z, 1.0f);               // :79
@@ -482,8 +555,7 @@ __global__ __launch_bounds__(256) void k_raster_tile(szg_image depth, szg_image 
 
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_shadow_tile(const ShadowGen* __restrict__ gen, const PrimRec* __restrict__ prims,
-                                                     const uint2* __restrict__ boxes, const uint2* __restrict__ chunkBoxes,
-                                                     unsigned primCount, float biasConstant, float biasSlope)
+                                                     Hierarchy hier, float biasConstant, float biasSlope)
 {
     if (gen->map == nullptr)
     {
@@ -505,7 +577,7 @@ __global__ __launch_bounds__(256) void k_shadow_tile(const ShadowGen* __restrict
     float const px = (float)x + 0.5f, py = (float)y + 0.5f;
     bool const biased = biasConstant != 0.0f || biasSlope != 0.0f;
     float best = 0.0f; // cleared depth; compare GREATER_OR_EQUAL (pipelines.cpp:663)
-    walkPrimitives(chunkBoxes, boxes, primCount, x0, x1, y0, y1, [&](unsigned p) {
+    walkPrimitives(hier, x0, x1, y0, y1, [&](unsigned p) {
         const PrimRec* t = prims + p;
         float e[3];
         edgeFunctions(t, px, py, e);
@@ -538,31 +610,58 @@ __global__ __launch_bounds__(256) void k_shadow_tile(const ShadowGen* __restrict
 }
 
 // ---------------------------------------------------------------------------
+namespace
+{
+Hierarchy hierarchyOf(const RasterBuffers& b, unsigned primCount)
+{
+    return Hierarchy{b.superBoxes, b.chunkBoxes, b.orderedBoxes, b.order, primCount};
+}
+} // namespace
+
+// Setup + (sort) + box hierarchy for `primCount` primitives; afterwards b.order is the walk order.
 hipError_t launch_raster_setup(hipStream_t s, bool shadow, const RasterDraw* d_draws, unsigned drawCount, unsigned primCount,
                                const szg_camera_packed* d_cam, unsigned camIndex, const ShadowGen* d_gen, unsigned W, unsigned H,
-                               PrimRec* d_prims, uint2* d_boxes, uint2* d_chunkBoxes)
+                               RasterBuffers& b)
 {
     if (primCount == 0u)
     {
         return hipSuccess;
     }
     unsigned const chunks = (primCount + 63u) / 64u;
+    b.order = b.valsA;
     if (shadow)
     {
         hipLaunchKernelGGL(k_raster_setup<true>, dim3(chunks), dim3(64), 0, s, d_draws, drawCount, primCount, d_cam, camIndex, d_gen, W, H,
-                           d_prims, d_boxes, d_chunkBoxes);
+                           b.prims, b.boxes, b.keysA, b.valsA);
     }
     else
     {
         hipLaunchKernelGGL(k_raster_setup<false>, dim3(chunks), dim3(64), 0, s, d_draws, drawCount, primCount, d_cam, camIndex, d_gen, W, H,
-                           d_prims, d_boxes, d_chunkBoxes);
+                           b.prims, b.boxes, b.keysA, b.valsA);
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess)
+    {
+        return e;
+    }
+    // Few primitives: every patch can afford to look at all chunk boxes, keep the submission order.
+    if (primCount > RASTER_SORT_THRESHOLD)
+    {
+        e = raster_sort_pairs(s, b.sortTemp, b.sortTempBytes, b.keysA, b.keysB, b.valsA, b.valsB, primCount);
+        if (e != hipSuccess)
+        {
+            return e;
+        }
+        b.order = b.valsB;
+    }
+    hipLaunchKernelGGL(k_raster_chunks, dim3(chunks), dim3(64), 0, s, b.order, b.boxes, primCount, b.orderedBoxes, b.chunkBoxes);
+    hipLaunchKernelGGL(k_raster_superchunks, dim3((chunks + 63u) / 64u), dim3(64), 0, s, b.chunkBoxes, chunks, b.superBoxes);
     return hipGetLastError();
 }
 
 hipError_t launch_raster_tile(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
-                              const szg_gbuffer& g, const RasterDraw* d_draws, const PrimRec* d_prims, const uint2* d_boxes,
-                              const uint2* d_chunkBoxes, unsigned primCount, const szg_camera_packed* d_cam, unsigned camIndex)
+                              const szg_gbuffer& g, const RasterDraw* d_draws, const RasterBuffers& b, unsigned primCount,
+                              const szg_camera_packed* d_cam, unsigned camIndex)
 {
     unsigned const rows = tile.nranks <= 1u ? drawH : tile.local_rows;
     if (rows == 0u || drawW == 0u)
@@ -572,20 +671,19 @@ hipError_t launch_raster_tile(hipStream_t s, const szg_scene_texture& scene, uns
     dim3 const grid((drawW + 31u) / 32u, (rows + 7u) / 8u);
     RowMap const rm{tile.block_rows, tile.rank, tile.nranks};
     hipLaunchKernelGGL(k_raster_tile, grid, dim3(256), 0, s, scene.depth, g.diffuse, g.specular, g.normal, g.worldPosition,
-                       g.occlusionRoughnessMetallic, drawW, drawH, rows, rm, d_draws, d_prims, d_boxes, d_chunkBoxes, primCount, d_cam,
-                       camIndex);
+                       g.occlusionRoughnessMetallic, drawW, drawH, rows, rm, d_draws, b.prims, hierarchyOf(b, primCount), d_cam, camIndex);
     return hipGetLastError();
 }
 
-hipError_t launch_shadow_tile(hipStream_t s, const ShadowGen* d_gen, unsigned dim, const PrimRec* d_prims, const uint2* d_boxes,
-                              const uint2* d_chunkBoxes, unsigned primCount, float biasConstant, float biasSlope)
+hipError_t launch_shadow_tile(hipStream_t s, const ShadowGen* d_gen, unsigned dim, const RasterBuffers& b, unsigned primCount,
+                              float biasConstant, float biasSlope)
 {
     if (dim == 0u)
     {
         return hipSuccess;
     }
-    hipLaunchKernelGGL(k_shadow_tile, dim3((dim + 31u) / 32u, (dim + 7u) / 8u), dim3(256), 0, s, d_gen, d_prims, d_boxes, d_chunkBoxes,
-                       primCount, biasConstant, biasSlope);
+    hipLaunchKernelGGL(k_shadow_tile, dim3((dim + 31u) / 32u, (dim + 7u) / 8u), dim3(256), 0, s, d_gen, b.prims, hierarchyOf(b, primCount),
+                       biasConstant, biasSlope);
     return hipGetLastError();
 }
 } // namespace szg

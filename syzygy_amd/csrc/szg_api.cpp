@@ -276,10 +276,7 @@ struct szg_deferred
     // compute rasteriser (szg/raster.h): buffers grow on demand and are kept
     szg::RasterDraw* d_rasterDraws = nullptr;
     size_t rasterDrawCapacity = 0;
-    szg::PrimRec* d_prims = nullptr;
-    uint2* d_primBoxes = nullptr;
-    uint2* d_chunkBoxes = nullptr;
-    size_t primCapacity = 0;
+    szg::RasterBuffers raster;
 };
 
 extern "C" {
@@ -780,8 +777,10 @@ void szg_deferred_destroy(szg_deferred_t* p)
             (void)hipFree(plane);
         }
     }
-    void* const rest[] = {p->d_ownedShadowMaps, p->d_spots,       p->d_slots, p->d_lightRecs,  p->d_boxes,     p->d_ownedSlots,
-                          p->d_shadowGen,       p->d_rasterDraws, p->d_prims, p->d_primBoxes,  p->d_chunkBoxes};
+    szg::RasterBuffers const& rb = p->raster;
+    void* const rest[] = {p->d_ownedShadowMaps, p->d_spots,  p->d_slots, p->d_lightRecs, p->d_boxes,     p->d_ownedSlots,  p->d_shadowGen,
+                          p->d_rasterDraws,     rb.prims,    rb.boxes,   rb.keysA,       rb.keysB,       rb.valsA,         rb.valsB,
+                          rb.orderedBoxes,      rb.chunkBoxes, rb.superBoxes, rb.sortTemp};
     for (void* r : rest)
     {
         if (r != nullptr)
@@ -1182,10 +1181,12 @@ int ensure_raster_capacity(szg_deferred* p, hipStream_t s, size_t draws, size_t 
         SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_rasterDraws), n * sizeof(szg::RasterDraw)));
         p->rasterDrawCapacity = n;
     }
-    if (prims > p->primCapacity)
+    szg::RasterBuffers& rb = p->raster;
+    if (prims > rb.capacity)
     {
         SZG_HIP(hipStreamSynchronize(s));
-        void* const old[] = {p->d_prims, p->d_primBoxes, p->d_chunkBoxes};
+        void* const old[] = {rb.prims, rb.boxes, rb.keysA, rb.keysB, rb.valsA, rb.valsB, rb.orderedBoxes, rb.chunkBoxes, rb.superBoxes,
+                             rb.sortTemp};
         for (void* o : old)
         {
             if (o != nullptr)
@@ -1193,15 +1194,21 @@ int ensure_raster_capacity(szg_deferred* p, hipStream_t s, size_t draws, size_t 
                 (void)hipFree(o);
             }
         }
-        p->d_prims = nullptr;
-        p->d_primBoxes = nullptr;
-        p->d_chunkBoxes = nullptr;
-        p->primCapacity = 0;
-        size_t const n = ((prims * 3u / 2u) + 63u) / 64u * 64u;
-        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_prims), n * sizeof(szg::PrimRec)));
-        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_primBoxes), n * sizeof(uint2)));
-        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_chunkBoxes), (n / 64u) * sizeof(uint2)));
-        p->primCapacity = n;
+        rb = szg::RasterBuffers{};
+        size_t const n = ((prims * 3u / 2u) + 4095u) / 4096u * 4096u;
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.prims), n * sizeof(szg::PrimRec)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.boxes), n * sizeof(uint2)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.keysA), n * sizeof(unsigned)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.keysB), n * sizeof(unsigned)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.valsA), n * sizeof(unsigned)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.valsB), n * sizeof(unsigned)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.orderedBoxes), n * sizeof(uint2)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.chunkBoxes), (n / 64u) * sizeof(uint2)));
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&rb.superBoxes), (n / 4096u) * sizeof(uint2)));
+        // radix-sort temp storage for up to n pairs (a function of the count only)
+        SZG_HIP(szg::raster_sort_temp_bytes((unsigned)n, rb.sortTempBytes));
+        SZG_HIP(hipMalloc(&rb.sortTemp, rb.sortTempBytes > 0u ? rb.sortTempBytes : 16u));
+        rb.capacity = n;
     }
     return SZG_OK;
 }
@@ -1273,9 +1280,9 @@ int szg_deferred_record_gbuffer_raster(szg_deferred_t* p, void* stream, szg_rect
         return rc;
     }
     SZG_HIP(szg::launch_raster_setup(s, false, p->d_rasterDraws, (unsigned)draws.size(), primCount, d_cameras, view_camera_index, nullptr,
-                                     draw_rect.width, draw_rect.height, p->d_prims, p->d_primBoxes, p->d_chunkBoxes));
-    SZG_HIP(szg::launch_raster_tile(s, *scene_texture, draw_rect.width, draw_rect.height, t, p->gbuffer, p->d_rasterDraws, p->d_prims,
-                                    p->d_primBoxes, p->d_chunkBoxes, primCount, d_cameras, view_camera_index));
+                                     draw_rect.width, draw_rect.height, p->raster));
+    SZG_HIP(szg::launch_raster_tile(s, *scene_texture, draw_rect.width, draw_rect.height, t, p->gbuffer, p->d_rasterDraws, p->raster,
+                                    primCount, d_cameras, view_camera_index));
     return SZG_OK;
 }
 
@@ -1336,9 +1343,9 @@ int szg_deferred_record_shadow_raster(szg_deferred_t* p, void* stream, const szg
     {
         // the primitive buffers are reused slot after slot: stream order keeps setup(k+1) behind tile(k)
         SZG_HIP(szg::launch_raster_setup(s, true, p->d_rasterDraws, (unsigned)draws.size(), primCount, nullptr, 0u, p->d_shadowGen + slot, dim,
-                                         dim, p->d_prims, p->d_primBoxes, p->d_chunkBoxes));
-        SZG_HIP(szg::launch_shadow_tile(s, p->d_shadowGen + slot, dim, p->d_prims, p->d_primBoxes, p->d_chunkBoxes, primCount,
-                                        p->config.depthBiasConstant, p->config.depthBiasSlope));
+                                         dim, p->raster));
+        SZG_HIP(szg::launch_shadow_tile(s, p->d_shadowGen + slot, dim, p->raster, primCount, p->config.depthBiasConstant,
+                                        p->config.depthBiasSlope));
     }
     return SZG_OK;
 }

@@ -109,14 +109,37 @@ struct PrimRec
     uint32_t pad[2];
 };
 static_assert(sizeof(PrimRec) == 80, "PrimRec layout");
+// Device buffers of one raster pass, owned by the pipeline and grown on demand (szg_api.cpp).
+struct RasterBuffers
+{
+    PrimRec* prims = nullptr;       // [capacity] submission order
+    uint2* boxes = nullptr;         // [capacity] pixel boxes, submission order (x: min | max << 16, y likewise)
+    unsigned* keysA = nullptr;      // [capacity] sort keys / scratch
+    unsigned* keysB = nullptr;
+    unsigned* valsA = nullptr;      // [capacity] identity order
+    unsigned* valsB = nullptr;      // [capacity] sorted order
+    uint2* orderedBoxes = nullptr;  // [capacity] boxes in walk order
+    uint2* chunkBoxes = nullptr;    // [capacity / 64]
+    uint2* superBoxes = nullptr;    // [capacity / 4096 + 1]
+    void* sortTemp = nullptr;
+    size_t sortTempBytes = 0;
+    const unsigned* order = nullptr; // valsA or valsB: set by launch_raster_setup
+    size_t capacity = 0;
+};
+// above this many primitives the boxes are radix-sorted (size class, Morton code) before the hierarchy is built
+constexpr unsigned RASTER_SORT_THRESHOLD = 4096u;
+// kernels_raster_sort.hip (rocPRIM): temp-storage size for `n` pairs, and the sort itself
+hipError_t raster_sort_temp_bytes(unsigned n, size_t& bytes);
+hipError_t raster_sort_pairs(hipStream_t s, void* temp, size_t tempBytes, const unsigned* keysIn, unsigned* keysOut,
+                             const unsigned* valsIn, unsigned* valsOut, unsigned n);
 hipError_t launch_raster_setup(hipStream_t s, bool shadow, const RasterDraw* d_draws, unsigned drawCount, unsigned primCount,
                                const szg_camera_packed* d_cam, unsigned camIndex, const ShadowGen* d_gen, unsigned W, unsigned H,
-                               PrimRec* d_prims, uint2* d_boxes, uint2* d_chunkBoxes);
+                               RasterBuffers& b);
 hipError_t launch_raster_tile(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
-                              const szg_gbuffer& g, const RasterDraw* d_draws, const PrimRec* d_prims, const uint2* d_boxes,
-                              const uint2* d_chunkBoxes, unsigned primCount, const szg_camera_packed* d_cam, unsigned camIndex);
-hipError_t launch_shadow_tile(hipStream_t s, const ShadowGen* d_gen, unsigned dim, const PrimRec* d_prims, const uint2* d_boxes,
-                              const uint2* d_chunkBoxes, unsigned primCount, float biasConstant, float biasSlope);
+                              const szg_gbuffer& g, const RasterDraw* d_draws, const RasterBuffers& b, unsigned primCount,
+                              const szg_camera_packed* d_cam, unsigned camIndex);
+hipError_t launch_shadow_tile(hipStream_t s, const ShadowGen* d_gen, unsigned dim, const RasterBuffers& b, unsigned primCount,
+                              float biasConstant, float biasSlope);
 hipError_t launch_oetf(hipStream_t s, const szg_image& image, unsigned width, unsigned height, unsigned function);
 hipError_t launch_compose_rowtiles(hipStream_t s, const void* gathered, size_t tileStrideBytes, unsigned nranks,
                                    unsigned blockRows, const szg_image& dst, unsigned width, unsigned height);
