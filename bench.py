@@ -301,6 +301,41 @@ def main():
             "achieved_GBps": bytes_composite / (fast_ms / 1e3) / 1e9, "frac_of_8TBps": bytes_composite / (fast_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
             "frame_ms_with_fast_mode": per["lights"] + per["transmittance"] + per["skyview"] + aerial_ms + fast_ms}
 
+    if world == 1 and not tiled:
+        # The pass right before the path: the G-buffer raster of the same scene given as real meshes
+        # (instanced cubes + ground quad) into a second target. Producer of the path's inputs: never part of `value`.
+        from syzygy_amd import meshes as mesh_lib
+
+        scene_meshes = mesh_lib.meshes_of_fill_scene(syn.fill)
+        raster_target = pl.SceneTexture(W, H, dev)
+        raster_pipe = pl.DeferredShadingPipeline((W, H), max_spot_lights=1, max_shadow_maps=0, device_index=local_rank)
+        marr = mesh_lib.mesh_array(scene_meshes, dev)
+        st = raster_target.abi()
+        from syzygy_amd import lib as _lib
+        from syzygy_amd._lib import check as _check
+        import ctypes as _C
+
+        def raster_once():
+            _check(_lib().szg_deferred_record_gbuffer_raster(raster_pipe._h, pl._stream_handle(None), rect, None, _C.byref(st), 0,
+                                                             _C.c_void_p(cameras.deviceAddress()), marr, len(scene_meshes)))
+
+        raster_once()
+        torch.cuda.synchronize()
+        reps = 10
+        r0, r1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        r0.record()
+        for _ in range(reps):
+            raster_once()
+        r1.record()
+        torch.cuda.synchronize()
+        raster_ms = r0.elapsed_time(r1) / reps
+        prims = sum(len(m.indices) // 3 * len(m.models) for m in scene_meshes)
+        out["gbuffer_raster_pass"] = {"kernels": "k_raster_setup + k_raster_chunks + k_raster_superchunks + k_raster_tile", "primitives": prims,
+                                      "ms": raster_ms, "algorithmic_bytes": 52 * W * H,
+                                      "achieved_GBps": 52 * W * H / (raster_ms / 1e3) / 1e9,
+                                      "frac_of_8TBps": 52 * W * H / (raster_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "in_value": False}
+        raster_pipe.cleanup()
+
     if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
         out["cpu_baseline"] = cpu_baseline(args, wl, atm, cam, sun, moon, spots, syn)
     if rank == 0:
