@@ -2,18 +2,127 @@
 // written against include/szg/pipelines.hpp. Renders one frame and writes the RGBA16 scene
 // colour to argv[1]; tests/test_gpu_cpp_shim.py compares it with the Python path / oracle.
 #include <cstdio>
+#include <cstring>
 #include <vector>
 
 #include "szg/pipelines.hpp"
+
+namespace
+{
+// Device copy of a host array (the test's stand-in for the engine's GPU mesh / texture buffers).
+template <typename T> T* upload(std::vector<T> const& host)
+{
+    T* d = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d), host.size() * sizeof(T)) != hipSuccess ||
+        hipMemcpy(d, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice) != hipSuccess)
+    {
+        return nullptr;
+    }
+    return d;
+}
+
+// The editor's start-up scene (editor.cpp:500-545) from the asset library's built-in cube / plane and default
+// material maps (assets.cpp:1294-1610), as szg_mesh_instanced records.
+struct DefaultScene
+{
+    std::vector<szg_surface> cubeSurfaces, planeSurfaces;
+    std::vector<szg_mesh_instanced> meshes;
+
+    bool build()
+    {
+        auto vertex = [](float x, float y, float z, float u, float v, float nx, float ny, float nz) {
+            return szg_vertex_packed{{x, y, z}, u, {nx, ny, nz}, v, {1.0f, 1.0f, 1.0f, 1.0f}};
+        };
+        std::vector<szg_vertex_packed> plane{vertex(-1, 0, 1, 0, 0, 0, -1, 0), vertex(1, 0, 1, 1, 0, 0, -1, 0),
+                                             vertex(1, 0, -1, 1, 1, 0, -1, 0), vertex(-1, 0, -1, 0, 1, 0, -1, 0)};
+        std::vector<uint32_t> planeIndices{0, 1, 3, 1, 2, 3};
+        struct Face
+        {
+            float o[3], ex[3], ey[3], n[3];
+        };
+        Face const faces[6] = {{{-1, -1, 1}, {2, 0, 0}, {0, 0, -2}, {0, -1, 0}}, {{-1, 1, -1}, {2, 0, 0}, {0, 0, 2}, {0, 1, 0}},
+                               {{1, -1, -1}, {0, 0, 2}, {0, 2, 0}, {1, 0, 0}},   {{-1, -1, 1}, {0, 0, -2}, {0, 2, 0}, {-1, 0, 0}},
+                               {{-1, -1, -1}, {2, 0, 0}, {0, 2, 0}, {0, 0, -1}}, {{1, -1, 1}, {-2, 0, 0}, {0, 2, 0}, {0, 0, 1}}};
+        std::vector<szg_vertex_packed> cube;
+        std::vector<uint32_t> cubeIndices;
+        for (Face const& f : faces)
+        {
+            uint32_t const base = (uint32_t)cube.size();
+            float const uv[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+            for (auto const& c : uv)
+            {
+                cube.push_back(vertex(f.o[0] + c[0] * f.ex[0] + c[1] * f.ey[0], f.o[1] + c[0] * f.ex[1] + c[1] * f.ey[1],
+                                      f.o[2] + c[0] * f.ex[2] + c[1] * f.ey[2], c[0], c[1], f.n[0], f.n[1], f.n[2]));
+            }
+            for (uint32_t i : {0u, 1u, 2u, 0u, 2u, 3u})
+            {
+                cubeIndices.push_back(base + i);
+            }
+        }
+        // default maps: 64x64 RGBA8
+        uint32_t const N = 64;
+        std::vector<uint8_t> color(N * N * 4), normal(N * N * 4), orm(N * N * 4);
+        for (uint32_t y = 0; y < N; y++)
+        {
+            for (uint32_t x = 0; x < N; x++)
+            {
+                uint8_t const grey = ((x / 4 + y / 4) % 2 == 0) ? 200 : 100;
+                uint8_t* c = &color[(y * N + x) * 4];
+                c[0] = c[1] = c[2] = grey;
+                c[3] = 255;
+                uint8_t* n = &normal[(y * N + x) * 4];
+                n[0] = n[1] = 127;
+                n[2] = 255;
+                n[3] = 0;
+                uint8_t* o = &orm[(y * N + x) * 4];
+                o[0] = 255;
+                o[1] = 60;
+                o[2] = o[3] = 0;
+            }
+        }
+        szg_material material{};
+        material.color = szg_texture{upload(color), N, N, N * 4, 0};
+        material.normal = szg_texture{upload(normal), N, N, N * 4, 0};
+        material.orm = szg_texture{upload(orm), N, N, N * 4, 0};
+        cubeSurfaces = {szg_surface{0, (uint32_t)cubeIndices.size(), material}};
+        planeSurfaces = {szg_surface{0, (uint32_t)planeIndices.size(), material}};
+
+        auto instance = [&](std::vector<szg_vertex_packed> const& v, std::vector<uint32_t> const& idx, std::vector<szg_surface> const& surfaces,
+                            float tx, float ty, float tz, float sx, float sy, float sz) {
+            float const t[3] = {tx, ty, tz}, e[3] = {0, 0, 0}, sc[3] = {sx, sy, sz};
+            std::vector<szg_mat4> model(1), mit(1);
+            szg_transform_matrix(t, e, sc, &model[0]);         // Transform::toMatrix, scene.cpp:207
+            szg_mat4_inverse_transpose(&model[0], &mit[0]);    // scene.cpp:210
+            szg_mesh_instanced m{};
+            m.d_vertices = upload(v);
+            m.vertex_count = (uint32_t)v.size();
+            m.d_indices = upload(idx);
+            m.index_count = (uint32_t)idx.size();
+            m.surfaces = surfaces.data();
+            m.surface_count = (uint32_t)surfaces.size();
+            m.d_models = upload(model);
+            m.d_model_inverse_transposes = upload(mit);
+            m.instance_count = 1;
+            m.render = 1;
+            m.casts_shadow = 1;
+            meshes.push_back(m);
+            return m.d_vertices != nullptr && m.d_indices != nullptr && m.d_models != nullptr && m.d_model_inverse_transposes != nullptr;
+        };
+        return instance(cube, cubeIndices, cubeSurfaces, 0, -8, 6, 5, 5, 5) && instance(cube, cubeIndices, cubeSurfaces, 0, -8, -6, 5, 5, 5) &&
+               instance(plane, planeIndices, planeSurfaces, 0, -1, 0, 20, 1, 20) && material.color.data != nullptr;
+    }
+};
+} // namespace
 
 int main(int argc, char** argv)
 {
     if (argc < 4)
     {
-        std::fprintf(stderr, "usage: record_draw out.bin width height\n");
+        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes]\n");
         return 2;
     }
     uint32_t const W = (uint32_t)std::atoi(argv[2]), H = (uint32_t)std::atoi(argv[3]);
+    bool const realMeshes = argc > 4 && std::strcmp(argv[4], "meshes") == 0;
 
     // scene -> packed blocks (renderer.cpp:302-342)
     szg_camera camera;
@@ -43,7 +152,7 @@ int main(int argc, char** argv)
     auto atmospheres = szg::TStagedBuffer<szg::AtmospherePacked>::allocate(1);
     auto lights = szg::TStagedBuffer<szg::DirectionalLightPacked>::allocate(2);
     auto sceneTexture = szg::SceneTexture::create(W, H);
-    szg::DeferredShadingPipeline deferred(W, H, 16, 10, 0);
+    szg::DeferredShadingPipeline deferred(W, H, 16, 10, realMeshes ? 512 : 0);
     auto skyView = szg::SkyViewComputePipeline::create();
     if (!cameras.valid() || !atmospheres.valid() || !lights.valid() || !sceneTexture || !deferred.valid() || !skyView)
     {
@@ -67,7 +176,22 @@ int main(int argc, char** argv)
     szg_rect const sceneSubregion{0, 0, W, H};
 
     // renderer.cpp:383-415
-    deferred.recordDrawCommands(cmd, sceneSubregion, *sceneTexture, 1, lights, spotlights, 0, cameras, &geometry);
+    DefaultScene scene;
+    if (realMeshes)
+    {
+        if (!scene.build())
+        {
+            std::fprintf(stderr, "mesh upload failed\n");
+            return 1;
+        }
+        // the reference's own call shape: std::span<MeshInstanced const> sceneGeometry (shadow maps are rendered too)
+        deferred.recordDrawCommands(cmd, sceneSubregion, *sceneTexture, 1, lights, spotlights, 0, cameras,
+                                    std::span<szg_mesh_instanced const>{scene.meshes});
+    }
+    else
+    {
+        deferred.recordDrawCommands(cmd, sceneSubregion, *sceneTexture, 1, lights, spotlights, 0, cameras, &geometry);
+    }
     skyView->recordDrawCommands(cmd, *sceneTexture, sceneSubregion, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0,
                                 cameras, 0, lights);
     if (hipStreamSynchronize(cmd) != hipSuccess)

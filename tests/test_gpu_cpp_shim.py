@@ -54,3 +54,46 @@ def test_cpp_record_draw_matches_oracle(tmp_path):
     ob.composite(frame, rect, None, None, atm, cam, dirs, 0, tl, sl, threads=8)
     assert np.abs(got.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
     assert (got[..., 3] == 65535).all() and got[..., :3].any()
+
+
+def test_cpp_record_draw_with_real_meshes_matches_oracle(tmp_path):
+    """The same C++ caller with the reference's own argument, a span of mesh instances (the editor's start-up scene built
+    in C++): shadow raster into 512^2 maps, G-buffer raster, lights, sky-view pipeline — against the oracle chain."""
+    import ctypes as C
+
+    from oracle import binding as ob
+    from syzygy_amd import abi, lib, meshes, scene
+
+    exe = os.path.join(HERE, "cpp", "record_draw")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(HERE, "cpp")], check=True)
+    W, H, DIM = 200, 120, 512
+    out = tmp_path / "frame_meshes.bin"
+    r = subprocess.run([exe, str(out), str(W), str(H), "meshes"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(out, dtype=np.uint16).reshape(H, W, 4)
+
+    cam = scene.camera_packed(scene.default_camera(), np.float32(W) / np.float32(H))
+    a = scene.default_atmosphere()
+    a.sunEulerAngles[0] = np.float32(np.float32(3.14159265358979) + np.float32(35.0) * np.float32(3.14159265358979) / np.float32(180.0))
+    atm, sun, moon = scene.atmosphere_baked(a, scene.aabb((0.0, -7.0, 39.0), (64.0, 8.0, 46.0)))
+    spot = scene.make_spot((1, 0, 0), (-20.0, -28.0, -20.0), scene.eulers_from_forward((20.0, 20.0, 20.0)))
+    spots = (abi.SpotLightPacked * 1)(spot)
+    ms = meshes.reference_default_scene()
+    maps = []
+    for light in (sun, moon, spot):
+        pv = abi.Mat4()
+        lib().szg_mat4_mul(C.byref(light.projection), C.byref(light.view), C.byref(pv))
+        maps.append(ob.shadow_raster(pv, DIM, ms, threads=8))
+    images = (abi.Image * len(maps))(*[ob.host_image(m, abi.SZG_FORMAT_D32_SFLOAT) for m in maps])
+    host_maps = abi.ShadowMaps(len(maps), 0, C.cast(images, C.POINTER(abi.Image)))
+    rect = abi.Rect(0, 0, W, H)
+    frame = ob.HostFrame(W, H)
+    dirs = (abi.DirectionalLightPacked * 2)(sun, moon)
+    ob.gbuffer_raster(frame, rect, None, cam, ms, threads=8)
+    ob.lights(frame, rect, None, host_maps, cam, dirs, 2, 1, spots, 1, threads=8)
+    tl = ob.transmittance_lut(atm, 512, 128, threads=8)
+    sl = ob.skyview_lut(atm, cam, tl, 2048, 1024, threads=16)
+    ob.composite(frame, rect, None, host_maps, atm, cam, dirs, 0, tl, sl, threads=8)
+    assert (frame.depth > 0).mean() > 0.1
+    assert np.abs(got.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
