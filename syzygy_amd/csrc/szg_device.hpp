@@ -224,6 +224,9 @@ SZG_DEV V4 unpack_half4(uint2 v)
 }
 SZG_DEV uint2 pack_half4(float r, float g, float b, float a)
 {
+    // The stored value is RNE(fp16) of the ROUNDED fp32 value. Keep the compiler from folding a producing fp32
+    // multiply into the conversion (v_fma_mixlo_f16 rounds the exact product once: a different result at ties).
+    asm volatile("" : "+v"(r), "+v"(g), "+v"(b), "+v"(a));
     __half2 const lo = __floats2half2_rn(r, g);
     __half2 const hi = __floats2half2_rn(b, a);
     uint2 o;

@@ -20,10 +20,11 @@ from syzygy_amd import abi, meshes, scene
 
 
 def _planes_equal(got, want):
+    """Bit equality; a NaN equals a NaN whatever its payload (x86 and gfx950 differ in the sign of a generated NaN)."""
     for name in ("diffuse", "specular", "normal", "worldPosition", "occlusionRoughnessMetallic"):
         a, b = got[name], want[name]
         bits = np.uint16 if a.dtype == np.float16 else np.uint32
-        same = a.view(bits) == b.view(bits)
+        same = (a.view(bits) == b.view(bits)) | (np.isnan(a) & np.isnan(b))
         assert same.all(), f"{name}: {(~same).sum()} of {same.size} values differ"
 
 
@@ -263,6 +264,47 @@ def test_gbuffer_raster_bit_exact(gpu, name, extent):
     assert (want.depth > 0).mean() > 0.05
     assert (depth.view(np.uint32) == want.depth.view(np.uint32)).all()
     _planes_equal(planes, want.planes())
+
+
+def _hostile_scene(seed, with_default=True):
+    """Degenerate and hostile geometry: zero-area and repeated-vertex triangles, constant uvs (singular cotangent frame),
+    NaN / inf / huge coordinates, an out-of-range index, a surface reaching past the index buffer, an instance-less and a
+    non-rendered mesh, a 1x1 and a missing texture."""
+    rng = np.random.default_rng(seed)
+    base = _soup(seed, 60)[0]
+    v = base.vertices.copy()
+    idx = base.indices.copy()
+    v["position"][3] = v["position"][4]                      # repeated vertex
+    v["position"][6:9] = v["position"][6]                    # zero area
+    v["uv_x"][9:12], v["uv_y"][9:12] = 0.25, 0.75            # constant uv: T = B = 0
+    v["position"][12] = (np.nan, 0.0, 1.0)
+    v["position"][15] = (np.inf, -np.inf, 3.0)
+    v["position"][18] = (1.0e30, -1.0e30, 1.0e30)
+    v["position"][21] = (1.0e-30, 1.0e-38, -1.0e-30)
+    idx[30] = 10 ** 9
+    tiny = {"color": (rng.integers(0, 256, (1, 1, 4), dtype=np.uint8), True), "normal": (rng.integers(0, 256, (1, 3, 4), dtype=np.uint8), False)}
+    half = len(idx) // 2
+    ident = meshes.transform_matrix()
+    squash = meshes.transform_matrix((0, -5, 10), (0.5, 1.0, 1.5), (3.0, 0.0, 3.0))  # singular model matrix
+    return [
+        meshes.MeshInstanced(v, idx, [(0, half, tiny), (half, 10 ** 6, meshes.default_material()), (10 ** 7, 30, tiny)], [ident, squash]),
+        meshes.MeshInstanced(v, idx, [(0, half, tiny)], [], name="no instances"),
+        meshes.MeshInstanced(v, idx, [(0, half, tiny)], [ident], render=False, name="hidden"),
+    ] + (meshes.reference_default_scene() if with_default else [])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,with_default", [(101, True), (202, False), (303, False)])
+def test_gbuffer_raster_hostile_geometry_bit_exact(gpu, seed, with_default):
+    W, H = 144, 81
+    inp = util.Inputs(W, H)
+    ms = _hostile_scene(seed, with_default)
+    planes, depth = _raster_gpu(gpu, W, H, inp.cam, ms)
+    want = ob.HostFrame(W, H)
+    ob.gbuffer_raster(want, inp.rect, None, inp.cam, ms, threads=8)
+    assert (depth.view(np.uint32) == want.depth.view(np.uint32)).all()
+    _planes_equal(planes, want.planes())
+    assert (want.depth > 0).mean() > 0.05
 
 
 @pytest.mark.gpu
