@@ -8,14 +8,15 @@ accidental change; they are data produced by this repository's own code:
 
 Contents: transmittance LUT 64x16 and the four corners + centre of the 256x64 and 512x128
 LUTs, a 64x32 sky-view LUT, and a 64x40 frame (G-buffer planes, depth, lights and composite
-results) at three sun elevations (70, 5, -3 degrees) with 6 spot lights.
+results) at three sun elevations (70, 5, -3 degrees) with 6 spot lights; the raster oracle's G-buffer of the
+editor's start-up scene (64x40) and one 64x64 sun shadow map of it.
 """
 import os
 
 import numpy as np
 
 from oracle import binding as ob
-from syzygy_amd import abi, scene  # noqa: F401
+from syzygy_amd import abi, meshes, scene  # noqa: F401
 from tests import util
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -48,6 +49,23 @@ def generate():
                 big = ob.transmittance_lut(inp.atm, w, h, threads=8)
                 pts = [(0, 0), (0, w - 1), (h - 1, 0), (h - 1, w - 1), (h // 2, w // 2), (h // 3, (2 * w) // 3)]
                 out[f"transmittance_{w}x{h}_probes"] = np.stack([big[y, x] for (y, x) in pts])
+    # raster oracle (oracle/szg_oracle_raster.cpp): the reference's default scene
+    import ctypes as C
+
+    from syzygy_amd import lib
+
+    inp = util.Inputs(64, 40, elevation_degrees=40.0, spots=0)
+    ms = meshes.reference_default_scene()
+    f = ob.HostFrame(64, 40)
+    ob.gbuffer_raster(f, inp.rect, None, inp.cam, ms)
+    out["raster_depth"] = f.depth.copy()
+    out["raster_position"] = f.position.copy()
+    out["raster_normal"] = f.normal.copy()
+    out["raster_diffuse"] = f.diffuse.copy()
+    out["raster_orm"] = f.orm.copy()
+    pv = abi.Mat4()
+    lib().szg_mat4_mul(C.byref(inp.sun.projection), C.byref(inp.sun.view), C.byref(pv))
+    out["raster_sun_shadow_64"] = ob.shadow_raster(pv, 64, ms)
     return out
 
 
