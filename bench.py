@@ -61,8 +61,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-tiled", action="store_true",
                     help="testing: run the row-tiled code path (collectives, compose) even with a single rank")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the product); gloo = host-staged rehearsal of the N-rank path")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal: every rank renders on cuda:0 (several ranks on a one-GPU box; needs --backend gloo)")
     ap.add_argument("--cpu-rows", type=int, default=540, help="rows of the frame the CPU baseline shades")
     args = ap.parse_args()
+
+    # The contract is ONE JSON line on stdout. Libraries write there too (RCCL prints its version banner to stdout on
+    # this image), so everything else is sent to stderr and the line goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -73,11 +83,18 @@ def main():
         raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    if args.same_device:
+        if args.backend != "gloo":
+            raise SystemExit("--same-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_tiled:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import __graft_entry__ as entry
 
@@ -204,8 +221,9 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    g = torch.tensor([geometry_px_local], dtype=torch.int64, device=dev)
+    red_dev = dev if args.backend == "nccl" else "cpu"
+    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
+    g = torch.tensor([geometry_px_local], dtype=torch.int64, device=red_dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if tiled:
@@ -269,13 +287,22 @@ def main():
         "scaling": "strong" if wl["tiled"] else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": wl["label"], "width": W, "height": H, "spot_lights": SPOTS, "geometry_fraction": G_frame / (W * H),
                    "sun_elevation_deg": args.elevation, "row_tile_block_rows": BLOCK_ROWS if tiled else None,
-                   "parallelism": (f"rowtile{nranks}+gather" if tiled else ("single" if world == 1 else f"replicas{world}"))},
+                   "parallelism": (f"rowtile{nranks}+gather" if tiled else ("single" if world == 1 else f"replicas{world}")),
+                   "collectives": (args.backend if (world > 1 or args.force_tiled) else None)},
         "pass_ms_rank0": per,
         "roofline": roofline,
         "roofline_valu": roofline_valu,
         "roofline_frame": {"algorithmic_bytes": frame_bytes, "device_ms": frame_s * 1e3,
                            "achieved_GBps": frame_bytes / frame_s / 1e9, "frac": frame_bytes / frame_s / 1e9 / HBM_PEAK_GBS},
     }
+
+    # Checksum of the final RGBA16 image (rank 0: the composed frame when tiled), outside the timed region: equal for
+    # every N and for the untiled run of the same workload — the row-tiled path changes no pixel.
+    if rank == 0:
+        final = composed if tiled else targets[(args.steps - 1) % len(targets)].color[:H]
+        img = final.view(torch.int16).to(torch.int64) & 0xFFFF
+        weights = (torch.arange(H, device=img.device, dtype=torch.int64) % 251 + 1).view(H, 1, 1)
+        out["image_checksum"] = {"sum": int(img.sum().item()), "row_weighted_sum": int((img * weights).sum().item())}
 
     if world == 1 and not tiled:
         # The pass right after the path, measured on its own outside the timed region: in-place
@@ -354,7 +381,8 @@ def main():
         out["cpu_baseline"] = cpu_baseline(args, wl, atm, cam, sun, moon, spots, syn)
     if rank == 0:
         log("per-pass device ms:", {k: round(v, 4) for k, v in per.items()})
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -50,6 +50,19 @@ def global_rows(height, rank, nranks, block_rows=DEFAULT_BLOCK_ROWS):
     return np.concatenate(out) if out else np.zeros((0,), np.int64)
 
 
+class _Done:
+    """Completed work handle (the host-staged gloo rehearsal path is synchronous)."""
+
+    def wait(self):
+        return True
+
+
+def _host_staged(tensor, group):
+    """gloo moves CUDA tensors only for some collectives: when N ranks are REHEARSED over gloo (CPU tests, or several
+    ranks sharing one GPU where RCCL refuses to run), the collectives below stage through host memory. RCCL never does."""
+    return tensor.is_cuda and dist.get_backend(group) == "gloo"
+
+
 def gather_tiles(local_color, rank, nranks, gathered=None, dst=0, group=None, async_op=False):
     """The one collective of the path. `local_color`: [stride_rows, W, 4] int16 (RGBA16 UNORM bits)
     on every rank; `gathered`: [nranks, stride_rows, W, 4] on `dst` (allocated if None). Returns
@@ -57,9 +70,19 @@ def gather_tiles(local_color, rank, nranks, gathered=None, dst=0, group=None, as
     must work.wait() before touching `gathered` or overwriting `local_color`."""
     # RCCL and gloo have no 16-bit integer type: move the tiles as bytes
     send = local_color.contiguous().view(torch.uint8)
+    if rank == dst and gathered is None:
+        gathered = torch.empty((nranks,) + tuple(local_color.shape), dtype=local_color.dtype, device=local_color.device)
+    if _host_staged(send, group):
+        host = send.cpu()
+        if rank == dst:
+            parts = [torch.empty_like(host) for _ in range(nranks)]
+            dist.gather(host, parts, dst=dst, group=group)
+            gathered.view(torch.uint8).copy_(torch.stack(parts))
+        else:
+            dist.gather(host, None, dst=dst, group=group)
+        out = gathered if rank == dst else None
+        return (out, _Done()) if async_op else out
     if rank == dst:
-        if gathered is None:
-            gathered = torch.empty((nranks,) + tuple(local_color.shape), dtype=local_color.dtype, device=local_color.device)
         work = dist.gather(send, list(gathered.view(torch.uint8).unbind(0)), dst=dst, group=group, async_op=async_op)
         return (gathered, work) if async_op else gathered
     work = dist.gather(send, None, dst=dst, group=group, async_op=async_op)
@@ -97,4 +120,9 @@ def allgather_lut(lut, rank, nranks, group=None, async_op=False, force=False):
     if nranks <= 1 and not force:
         return None
     b, e = lut_rows(lut.shape[0], rank, nranks)
+    if _host_staged(lut, group):
+        whole = torch.empty(lut.shape, dtype=lut.dtype)
+        dist.all_gather_into_tensor(whole.view(-1), lut[b:e].reshape(-1).cpu(), group=group)
+        lut.copy_(whole)
+        return _Done() if async_op else None
     return dist.all_gather_into_tensor(lut.view(-1), lut[b:e].reshape(-1).clone(), group=group, async_op=async_op)

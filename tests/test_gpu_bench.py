@@ -1,0 +1,38 @@
+"""bench.py contract on the GPU box: exactly one JSON line on stdout with the contract's keys, and the N-rank row-tiled
+frame loop rehearsed with two real processes (collectives staged over gloo because RCCL refuses two ranks on one GPU):
+the composed 8K image has the checksum of the single-GPU frame."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONTRACT_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline"]
+
+
+def _run(cmd):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [line for line in r.stdout.splitlines() if line.strip()]
+    assert len(lines) == 1, f"stdout must be ONE JSON line, got {len(lines)}: {r.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def test_bench_contract_and_two_rank_rehearsal():
+    one = _run([sys.executable, "bench.py", "--workload", "c4", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    for key in CONTRACT_KEYS:
+        assert key in one, key
+    assert one["n_gpus"] == 1 and one["unit"] == "Mpixels/s" and one["dtype"] == "f32" and one["vs_baseline"] is None
+    assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29655", "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "2", "--warmup", "1",
+                "--no-cpu-baseline"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["parallelism"] == "rowtile2+gather"
+    assert two["image_checksum"] == one["image_checksum"]
+    assert abs(two["config"]["geometry_fraction"] - one["config"]["geometry_fraction"]) < 1e-12
