@@ -308,6 +308,20 @@ def test_gbuffer_raster_hostile_geometry_bit_exact(gpu, seed, with_default):
 
 
 @pytest.mark.gpu
+def test_gbuffer_raster_4k_bit_exact(gpu):
+    """BASELINE config 3 size: the bench scene as meshes (290 primitives) at 3840x2160, whole frame against the oracle."""
+    W, H = 3840, 2160
+    inp = util.Inputs(W, H)
+    ms = meshes.meshes_of_fill_scene(inp.synthetic.fill)
+    planes, depth = _raster_gpu(gpu, W, H, inp.cam, ms)
+    want = ob.HostFrame(W, H)
+    ob.gbuffer_raster(want, inp.rect, None, inp.cam, ms, threads=16)
+    assert 0.55 < (want.depth > 0).mean() < 0.65
+    assert (depth.view(np.uint32) == want.depth.view(np.uint32)).all()
+    _planes_equal(planes, want.planes())
+
+
+@pytest.mark.gpu
 def test_gbuffer_raster_fullscreen_fan_is_watertight(gpu):
     W, H = 257, 131
     v, idx = _fullscreen_fan()
