@@ -308,6 +308,28 @@ def test_gbuffer_raster_hostile_geometry_bit_exact(gpu, seed, with_default):
 
 
 @pytest.mark.gpu
+def test_gbuffer_raster_without_geometry_clears_the_targets(gpu):
+    """No meshes / nothing rendered: the pass still clears the five planes and the depth (deferred.cpp:560-601)."""
+    W, H = 70, 33
+    inp = util.Inputs(W, H)
+    hidden = meshes.reference_default_scene()
+    for m in hidden:
+        m.render = False
+    for ms in ([], hidden):
+        target = gpu.pl.SceneTexture(W, H)
+        target.depth.fill_(3.0)
+        deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=1, max_shadow_maps=0)
+        deferred.upload_gbuffer({k: np.full((H, W, 4), 7, np.float16 if k != "worldPosition" else np.float32)
+                                 for k in ("diffuse", "specular", "normal", "worldPosition", "occlusionRoughnessMetallic")})
+        deferred.recordGBufferRaster(None, inp.rect, target, 0, _cameras(gpu, inp.cam), ms)
+        gpu.torch.cuda.synchronize()
+        assert (target.depth.cpu().numpy() == 0).all()
+        for name, plane in deferred.download_gbuffer(W, H).items():
+            assert (plane == 0).all(), name
+        deferred.cleanup()
+
+
+@pytest.mark.gpu
 def test_gbuffer_raster_4k_bit_exact(gpu):
     """BASELINE config 3 size: the bench scene as meshes (290 primitives) at 3840x2160, whole frame against the oracle."""
     W, H = 3840, 2160
