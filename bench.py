@@ -354,11 +354,10 @@ def main():
         st = raster_target.abi()
         from syzygy_amd import lib as _lib
         from syzygy_amd._lib import check as _check
-        import ctypes as _C
 
         def raster_once():
-            _check(_lib().szg_deferred_record_gbuffer_raster(raster_pipe._h, pl._stream_handle(None), rect, None, _C.byref(st), 0,
-                                                             _C.c_void_p(cameras.deviceAddress()), marr, len(scene_meshes)))
+            _check(_lib().szg_deferred_record_gbuffer_raster(raster_pipe._h, pl._stream_handle(None), rect, None, C.byref(st), 0,
+                                                             C.c_void_p(cameras.deviceAddress()), marr, len(scene_meshes)))
 
         raster_once()
         torch.cuda.synchronize()

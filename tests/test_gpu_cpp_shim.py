@@ -7,7 +7,6 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests import util
 
 pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -15,7 +14,6 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 
 def test_cpp_record_draw_matches_oracle(tmp_path):
     import ctypes as C
-    import math
 
     from oracle import binding as ob
     from syzygy_amd import abi, lib, scene

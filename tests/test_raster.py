@@ -16,7 +16,7 @@ import pytest
 
 from tests import util
 from oracle import binding as ob
-from syzygy_amd import abi, meshes, scene
+from syzygy_amd import abi, meshes
 
 
 def _planes_equal(got, want):

@@ -1,6 +1,4 @@
 """Shared helpers for the tests: seeded inputs and comparisons."""
-import ctypes as C
-
 import numpy as np
 
 from syzygy_amd import abi, scene
