@@ -11,6 +11,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1029,6 +1030,66 @@ int szg_deferred_record_draw_commands(szg_deferred_t* p, void* stream, szg_rect 
                                       view_camera_index, d_cameras);
 }
 
+} // extern "C"
+
+namespace
+{
+// Per-device OETF tables (one per transfer function), built on first use by k_oetf_table and kept for the life of
+// the process. `ready` orders later uses on other streams behind the build.
+struct OetfTables
+{
+    std::mutex lock;
+    unsigned short* table[16][2] = {};
+    hipEvent_t ready[16][2] = {};
+};
+OetfTables g_oetf;
+
+int oetf_table(hipStream_t s, unsigned function, const unsigned short** out)
+{
+    int device = 0;
+    SZG_HIP(hipGetDevice(&device));
+    if (device < 0 || device >= 16)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_record_oetf: device %d outside the table cache", device);
+    }
+    std::lock_guard<std::mutex> guard(g_oetf.lock);
+    if (g_oetf.table[device][function] == nullptr)
+    {
+        unsigned short* t = nullptr;
+        SZG_HIP(hipMalloc(reinterpret_cast<void**>(&t), 65536u * sizeof(unsigned short)));
+        hipEvent_t e = nullptr;
+        hipError_t err = hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (err == hipSuccess)
+        {
+            err = szg::launch_oetf_table(s, t, function);
+        }
+        if (err == hipSuccess)
+        {
+            err = hipEventRecord(e, s);
+        }
+        if (err != hipSuccess)
+        {
+            (void)hipFree(t);
+            if (e != nullptr)
+            {
+                (void)hipEventDestroy(e);
+            }
+            return fail_hip(err, "szg_record_oetf: building the transfer table");
+        }
+        g_oetf.table[device][function] = t;
+        g_oetf.ready[device][function] = e;
+    }
+    else
+    {
+        SZG_HIP(hipStreamWaitEvent(s, g_oetf.ready[device][function], 0));
+    }
+    *out = g_oetf.table[device][function];
+    return SZG_OK;
+}
+} // namespace
+
+extern "C" {
+
 int szg_record_oetf(void* stream, const szg_image* image, uint32_t width, uint32_t height, uint32_t transfer_function)
 {
     if (image == nullptr)
@@ -1051,7 +1112,13 @@ int szg_record_oetf(void* stream, const szg_image* image, uint32_t width, uint32
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_record_oetf: image rows must be 16-byte aligned");
     }
-    SZG_HIP(szg::launch_oetf(static_cast<hipStream_t>(stream), *image, width, height, transfer_function));
+    const unsigned short* table = nullptr;
+    int const rc = oetf_table(static_cast<hipStream_t>(stream), transfer_function, &table);
+    if (rc != SZG_OK)
+    {
+        return rc;
+    }
+    SZG_HIP(szg::launch_oetf(static_cast<hipStream_t>(stream), *image, width, height, table));
     return SZG_OK;
 }
 

@@ -140,7 +140,9 @@ hipError_t launch_raster_tile(hipStream_t s, const szg_scene_texture& scene, uns
                               const szg_camera_packed* d_cam, unsigned camIndex);
 hipError_t launch_shadow_tile(hipStream_t s, const ShadowGen* d_gen, unsigned dim, const RasterBuffers& b, unsigned primCount,
                               float biasConstant, float biasSlope);
-hipError_t launch_oetf(hipStream_t s, const szg_image& image, unsigned width, unsigned height, unsigned function);
+// `table`: 65536 x u16, the OETF of every UNORM16 channel value (launch_oetf_table fills it)
+hipError_t launch_oetf_table(hipStream_t s, unsigned short* table, unsigned function);
+hipError_t launch_oetf(hipStream_t s, const szg_image& image, unsigned width, unsigned height, const unsigned short* table);
 hipError_t launch_compose_rowtiles(hipStream_t s, const void* gathered, size_t tileStrideBytes, unsigned nranks,
                                    unsigned blockRows, const szg_image& dst, unsigned width, unsigned height);
 } // namespace szg
