@@ -78,7 +78,7 @@ SZG_DEV float safeSqrt(float v) { return sqrtf(fmaxf(v, 0.0f)); } // atmosphere/
 // special-case fix-up. The sequences below are the SAME algorithms without the scaling
 // (v_rcp_f32 / v_sqrt_f32 seed, Newton, exact fma residual corrections). They return the
 // IEEE-754 correctly rounded result — bit-identical to `/` and sqrtf() — whenever their
-// operand preconditions hold, and cost ~29 / ~39 cycles; a division whose denominator's
+// operand preconditions hold, and cost ~29 / ~26 cycles; a division whose denominator's
 // refined reciprocal is shared costs ~13. Checked on MI355X: sqrtN == sqrtf for ALL
 // binary32 inputs in its domain; divN == `/` on 4.3e9 random operand pairs with exponents
 // in [-60, 60] plus zero numerators (scratch history in DESIGN.md "lean exact ops").
@@ -104,17 +104,16 @@ SZG_DEV float divR(float a, float b, float y)
     return __builtin_copysignf(q, q0); // a zero quotient keeps the sign IEEE division gives it
 }
 SZG_DEV float divN(float a, float b) { return divR(a, b, rcpN(b)); }
-// sqrt(x); x == 0, x >= 2^-96 or +inf (negative / NaN -> NaN like sqrtf)
+// sqrt(x) for x == 0 or x in [2^-96, FLT_MAX] (NaN -> NaN): v_rsq_f32 seed, one Newton step on the exact fma residual.
+// Bit-identical to sqrtf for EVERY binary32 value of that domain (tools/verify_sqrt.hip, exhaustive on MI355X).
+// The max() only matters for x == 0: rsq stays finite, so 0 * y = 0 and the correction is fma(0, h, 0) = 0.
 SZG_DEV float sqrtN(float x)
 {
-    float s = __builtin_amdgcn_sqrtf(x);
-    float const sm = __builtin_bit_cast(float, __builtin_bit_cast(int, s) - 1);
-    float const sp = __builtin_bit_cast(float, __builtin_bit_cast(int, s) + 1);
-    float const rm = __builtin_fmaf(-sm, s, x);
-    float const rp = __builtin_fmaf(-sp, s, x);
-    s = (rm <= 0.0f) ? sm : s;
-    s = (rp > 0.0f) ? sp : s;
-    return s;
+    float const y = __builtin_amdgcn_rsqf(fmaxf(x, 0x1p-126f));
+    float const s = x * y;
+    float const h = 0.5f * y;
+    float const r = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(r, h, s);
 }
 template <bool LEAN> SZG_DEV float sqrtX(float x) { return LEAN ? sqrtN(x) : sqrtf(x); }
 template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
