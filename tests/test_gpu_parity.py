@@ -391,6 +391,42 @@ def test_generic_path_unusual_atmospheres(gpu, edit):
     assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_planets_cameras_and_suns(gpu, seed):
+    """Randomised frames: planet / shell size, density scales, coefficient magnitudes, sun elevation, camera height and
+    orientation drawn at random (some inside, some outside the domain of the lean exact ops). The chained frame must stay
+    within the north_star bound of the oracle; today it is bit-identical."""
+    from syzygy_amd import scene
+
+    rng = np.random.default_rng(1000 + seed)
+
+    def edit(a):
+        a.planetRadiusMegameters = float(rng.uniform(1.0, 12.0))
+        a.atmosphereRadiusMegameters = a.planetRadiusMegameters + float(rng.uniform(0.02, 0.4))
+        a.altitudeDecayRayleighMegameters = float(rng.uniform(0.002, 0.03))
+        a.altitudeDecayMieMegameters = float(rng.uniform(0.0005, 0.005))
+        for field in ("scatteringRayleighPerMegameter", "absorptionRayleighPerMegameter", "scatteringMiePerMegameter",
+                      "scatteringOzonePerMegameter", "absorptionOzonePerMegameter"):
+            scale = float(10.0 ** rng.uniform(-1.0, 1.0))
+            vals = getattr(a, field)
+            for k in range(3):
+                vals[k] = vals[k] * scale
+        a.sunAngularRadius = float(rng.uniform(0.002, 0.05))
+
+    cam = scene.default_camera()
+    cam.cameraPosition[:] = [float(rng.uniform(-30, 30)), float(-10.0 ** rng.uniform(0.3, 4.7)), float(rng.uniform(-40, 10))]
+    cam.eulerAngles[:] = [float(rng.uniform(-0.6, 0.6)), float(rng.uniform(-3.1, 3.1)), 0.0]
+    cam.fovDegrees = float(rng.uniform(30.0, 100.0))
+    inp = util.Inputs(112, 63, elevation_degrees=float(rng.uniform(-10.0, 90.0)), spots=int(rng.integers(0, 9)), camera=cam,
+                      atmosphere_edit=edit)
+    got, got_q = render_gpu(gpu, inp, lut=((128, 32), (128, 64)))
+    frame = render_oracle(gpu, inp, lut=((128, 32), (128, 64)))
+    assert_close(got, frame.debug, what=f"random frame {seed}")
+    assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+    exact = float((got.view(np.uint32) == frame.debug.view(np.uint32)).mean())
+    print(f"random frame {seed}: geometry {float((frame.depth > 0).mean()):.2f}, bit-identical fraction {exact:.5f}")
+
+
 def test_generic_path_camera_far_below_ground(gpu):
     """Unphysical on purpose (the reference has a TODO for it, common.glinl:294): rays whose radius drops under
     0.9 R_planet fail leanRay and use the generic operators; results still equal the oracle's, NaNs included."""
