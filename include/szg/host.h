@@ -100,6 +100,23 @@ void szg_transform_vk(const float position[3], const float eulers[3], szg_mat4* 
 void szg_view_vk(const float position[3], const float eulers[3], szg_mat4* out);
 /* geometry/transform.cpp:11-15 Transform::toMatrix (model matrix of a mesh instance, scene.cpp:205-211) */
 void szg_transform_matrix(const float translation[3], const float eulers[3], const float scale[3], szg_mat4* out);
+
+/* geometry/transform.hpp Transform */
+typedef struct szg_transform
+{
+    float translation[3];
+    float eulerAnglesRadians[3];
+    float scale[3];
+} szg_transform;
+/* renderer/scene.hpp:96-105 InstanceAnimation */
+#define SZG_INSTANCE_ANIMATION_NONE 0u
+#define SZG_INSTANCE_ANIMATION_DIAGONAL_WAVE 1u
+#define SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP 2u
+/* tickMeshInstance (scene.cpp:461-523): advance `transforms` of one MeshInstanced by its animation and refill the
+ * staged `models` / `modelInverseTransposes` arrays (count entries each) that the raster passes read. */
+void szg_tick_mesh_instance(uint32_t animation, const szg_transform* originals, szg_transform* transforms, uint32_t count,
+                            double time_elapsed_seconds, double delta_time_seconds, szg_mat4* out_models,
+                            szg_mat4* out_model_inverse_transposes);
 /* geometryhelpers.cpp:171-204 */
 void szg_projection_ortho_aabb_vk(const szg_mat4* view, const szg_aabb* bounds, szg_mat4* out);
 /* glm::inverse / glm::inverseTranspose / operator* on mat4 */

@@ -298,6 +298,15 @@ class SpotlightParams(C.Structure):
     ]
 
 
+class Transform(C.Structure):
+    _fields_ = [("translation", C.c_float * 3), ("eulerAnglesRadians", C.c_float * 3), ("scale", C.c_float * 3)]
+
+
+SZG_INSTANCE_ANIMATION_NONE = 0
+SZG_INSTANCE_ANIMATION_DIAGONAL_WAVE = 1
+SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP = 2
+
+
 class SunAnimation(C.Structure):
     _fields_ = [("frozen", C.c_uint32), ("time", C.c_float), ("speed", C.c_float), ("skipNight", C.c_uint32)]
 
@@ -391,6 +400,7 @@ HOST_FUNCTIONS = {
     "szg_transform_vk": (None, [P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_view_vk": (None, [P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_transform_matrix": (None, [P(C.c_float), P(C.c_float), P(C.c_float), P(Mat4)]),
+    "szg_tick_mesh_instance": (None, [U32, P(Transform), P(Transform), U32, C.c_double, C.c_double, P(Mat4), P(Mat4)]),
     "szg_projection_ortho_aabb_vk": (None, [P(Mat4), P(AABB), P(Mat4)]),
     "szg_mat4_inverse": (None, [P(Mat4), P(Mat4)]),
     "szg_mat4_inverse_transpose": (None, [P(Mat4), P(Mat4)]),

@@ -359,6 +359,37 @@ void szg_mat4_inverse(const szg_mat4* m, szg_mat4* out) { *out = inverse(*m); }
 void szg_mat4_inverse_transpose(const szg_mat4* m, szg_mat4* out) { *out = transpose(inverse(*m)); }
 void szg_mat4_mul(const szg_mat4* a, const szg_mat4* b, szg_mat4* out) { *out = mul(*a, *b); }
 
+// tickMeshInstance, scene.cpp:461-523
+void szg_tick_mesh_instance(uint32_t animation, const szg_transform* originals, szg_transform* transforms, uint32_t count,
+                            double time_elapsed_seconds, double delta_time_seconds, szg_mat4* out_models,
+                            szg_mat4* out_model_inverse_transposes)
+{
+    for (uint32_t i = 0; i < count; i++)
+    {
+        szg_transform const& original = originals[i];
+        szg_transform& current = transforms[i];
+        if (animation == SZG_INSTANCE_ANIMATION_DIAGONAL_WAVE)
+        {
+            // scene.cpp:490-500: the sum is float arithmetic, the division and the sine are double
+            float const diagonal = original.translation[0] - (-10.0f) + original.translation[2] - (-10.0f);
+            double const timeOffset = diagonal / 3.1415;
+            double const y = std::sin(time_elapsed_seconds + timeOffset);
+            current.translation[0] = original.translation[0] + 0.0f;
+            current.translation[1] = original.translation[1] + static_cast<float>(y);
+            current.translation[2] = original.translation[2] + 0.0f;
+        }
+        else if (animation == SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP)
+        {
+            current.eulerAnglesRadians[2] += static_cast<float>(delta_time_seconds); // scene.cpp:508-509
+        }
+    }
+    for (uint32_t i = 0; i < count; i++) // scene.cpp:515-522
+    {
+        szg_transform_matrix(transforms[i].translation, transforms[i].eulerAnglesRadians, transforms[i].scale, &out_models[i]);
+        szg_mat4_inverse_transpose(&out_models[i], &out_model_inverse_transposes[i]);
+    }
+}
+
 // scene.cpp:52-75
 void szg_atmosphere_default_earth(szg_atmosphere* a)
 {

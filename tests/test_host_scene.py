@@ -264,3 +264,38 @@ def test_spot_ring_is_deterministic():
     b = scene.spot_ring(16)
     assert bytes(a) == bytes(b)
     assert len({tuple(l.position) for l in a}) == 16
+
+
+def test_transform_matrix_and_mesh_instance_tick():
+    """Transform::toMatrix (transform.cpp:11-15) and tickMeshInstance (scene.cpp:461-523) against a float64 numpy
+    restatement: translate * orientate4 * scale, the diagonal wave y = sin(t + (x + 10 + z + 10) / 3.1415), the spin
+    eulers.z += dt, and modelInverseTranspose = transpose(inverse(model))."""
+    t, e, s = (3.0, -8.0, 6.0), (0.3, -0.2, 1.1), (5.0, 2.0, 0.5)
+    m = abi.Mat4()
+    lib().szg_transform_matrix(abi.f3(*t), abi.f3(*e), abi.f3(*s), C.byref(m))
+    want = np_translate(t) @ np_orientate4(e) @ np.diag([s[0], s[1], s[2], 1.0])
+    assert close(m.to_numpy(), want)
+
+    n = 3
+    originals = (abi.Transform * n)()
+    for i in range(n):
+        originals[i].translation[:] = [float(-4 + 5 * i), -8.0, float(2 - 3 * i)]
+        originals[i].eulerAnglesRadians[:] = [0.1 * i, 0.0, 0.2]
+        originals[i].scale[:] = [1.0 + i, 1.0, 2.0]
+    for animation in (abi.SZG_INSTANCE_ANIMATION_NONE, abi.SZG_INSTANCE_ANIMATION_DIAGONAL_WAVE,
+                      abi.SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP):
+        transforms = (abi.Transform * n)(*originals)
+        models, mits = (abi.Mat4 * n)(), (abi.Mat4 * n)()
+        elapsed, dt = 12.345, 0.016
+        lib().szg_tick_mesh_instance(animation, originals, transforms, n, elapsed, dt, models, mits)
+        for i in range(n):
+            tr = np.array(originals[i].translation, np.float64)
+            eu = np.array(originals[i].eulerAnglesRadians, np.float64)
+            if animation == abi.SZG_INSTANCE_ANIMATION_DIAGONAL_WAVE:
+                tr[1] += math.sin(elapsed + (tr[0] + 10.0 + tr[2] + 10.0) / 3.1415)
+            if animation == abi.SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP:
+                eu[2] += dt
+            assert close(np.array(transforms[i].translation), tr) and close(np.array(transforms[i].eulerAnglesRadians), eu)
+            want = np_translate(tr) @ np_orientate4(eu) @ np.diag(list(originals[i].scale) + [1.0])
+            assert close(models[i].to_numpy(), want, 1e-5)
+            assert close(mits[i].to_numpy(), np.linalg.inv(want).T, 1e-4)
