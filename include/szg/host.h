@@ -112,6 +112,23 @@ typedef struct szg_transform
 #define SZG_INSTANCE_ANIMATION_NONE 0u
 #define SZG_INSTANCE_ANIMATION_DIAGONAL_WAVE 1u
 #define SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP 2u
+/* One shadow-casting MeshInstanced for Scene::calculateShadowBounds: Mesh::vertexBounds + the instance transforms. */
+typedef struct szg_shadow_caster
+{
+    szg_aabb vertex_bounds;          /* assets.hpp:40 Mesh::vertexBounds (AABB::create(min, max) of the vertex positions) */
+    const szg_transform* transforms; /* MeshInstanced::transforms */
+    uint32_t transform_count;
+    uint32_t render;                 /* MeshInstanced::render */
+    uint32_t casts_shadow;           /* MeshInstanced::castsShadow */
+    uint32_t padding;
+} szg_shadow_caster;
+/* geometrytypes.cpp:11-19 AABB::create */
+void szg_aabb_create(const float min[3], const float max[3], szg_aabb* out);
+/* Scene::calculateShadowBounds (scene.cpp:95-148): the world AABB of every rendered shadow caster's transformed
+ * vertex-bounds corners; the `captured_bounds` of szg_atmosphere_baked / szg_make_directional. Returns 0 and leaves
+ * *out zeroed when no caster contributes (scene.cpp:138-143), 1 otherwise. */
+int szg_calculate_shadow_bounds(const szg_shadow_caster* casters, uint32_t caster_count, szg_aabb* out);
+
 /* tickMeshInstance (scene.cpp:461-523): advance `transforms` of one MeshInstanced by its animation and refill the
  * staged `models` / `modelInverseTransposes` arrays (count entries each) that the raster passes read. */
 void szg_tick_mesh_instance(uint32_t animation, const szg_transform* originals, szg_transform* transforms, uint32_t count,

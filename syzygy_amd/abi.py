@@ -302,6 +302,17 @@ class Transform(C.Structure):
     _fields_ = [("translation", C.c_float * 3), ("eulerAnglesRadians", C.c_float * 3), ("scale", C.c_float * 3)]
 
 
+class ShadowCaster(C.Structure):
+    _fields_ = [
+        ("vertex_bounds", AABB),
+        ("transforms", C.POINTER(Transform)),
+        ("transform_count", C.c_uint32),
+        ("render", C.c_uint32),
+        ("casts_shadow", C.c_uint32),
+        ("padding", C.c_uint32),
+    ]
+
+
 SZG_INSTANCE_ANIMATION_NONE = 0
 SZG_INSTANCE_ANIMATION_DIAGONAL_WAVE = 1
 SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP = 2
@@ -400,6 +411,8 @@ HOST_FUNCTIONS = {
     "szg_transform_vk": (None, [P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_view_vk": (None, [P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_transform_matrix": (None, [P(C.c_float), P(C.c_float), P(C.c_float), P(Mat4)]),
+    "szg_aabb_create": (None, [P(C.c_float), P(C.c_float), P(AABB)]),
+    "szg_calculate_shadow_bounds": (C.c_int, [P(ShadowCaster), U32, P(AABB)]),
     "szg_tick_mesh_instance": (None, [U32, P(Transform), P(Transform), U32, C.c_double, C.c_double, P(Mat4), P(Mat4)]),
     "szg_projection_ortho_aabb_vk": (None, [P(Mat4), P(AABB), P(Mat4)]),
     "szg_mat4_inverse": (None, [P(Mat4), P(Mat4)]),

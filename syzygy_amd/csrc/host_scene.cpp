@@ -359,6 +359,65 @@ void szg_mat4_inverse(const szg_mat4* m, szg_mat4* out) { *out = inverse(*m); }
 void szg_mat4_inverse_transpose(const szg_mat4* m, szg_mat4* out) { *out = transpose(inverse(*m)); }
 void szg_mat4_mul(const szg_mat4* a, const szg_mat4* b, szg_mat4* out) { *out = mul(*a, *b); }
 
+// geometrytypes.cpp:11-19
+void szg_aabb_create(const float mn[3], const float mx[3], szg_aabb* out)
+{
+    for (int k = 0; k < 3; k++)
+    {
+        float const safeMin = std::fmin(mn[k], mx[k]);
+        float const safeMax = std::fmax(mn[k], mx[k]);
+        float const center = 0.5f * (safeMax + safeMin);
+        out->center[k] = center;
+        out->half_extent[k] = safeMax - center;
+    }
+}
+
+// Scene::calculateShadowBounds, scene.cpp:95-148
+int szg_calculate_shadow_bounds(const szg_shadow_caster* casters, uint32_t caster_count, szg_aabb* out)
+{
+    std::memset(out, 0, sizeof *out);
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX};
+    float mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (uint32_t c = 0; c < caster_count; c++)
+    {
+        szg_shadow_caster const& caster = casters[c];
+        if (caster.casts_shadow == 0u || caster.render == 0u)
+        {
+            continue;
+        }
+        // AABB::collectVertices, geometrytypes.cpp:20-32
+        float corners[8][3];
+        for (int v = 0; v < 8; v++)
+        {
+            corners[v][0] = caster.vertex_bounds.center[0] + ((v & 4) ? -caster.vertex_bounds.half_extent[0] : caster.vertex_bounds.half_extent[0]);
+            corners[v][1] = caster.vertex_bounds.center[1] + ((v & 2) ? -caster.vertex_bounds.half_extent[1] : caster.vertex_bounds.half_extent[1]);
+            corners[v][2] = caster.vertex_bounds.center[2] + ((v & 1) ? -caster.vertex_bounds.half_extent[2] : caster.vertex_bounds.half_extent[2]);
+        }
+        for (uint32_t t = 0; t < caster.transform_count; t++)
+        {
+            szg_mat4 m;
+            szg_transform_matrix(caster.transforms[t].translation, caster.transforms[t].eulerAnglesRadians, caster.transforms[t].scale, &m);
+            for (int v = 0; v < 8; v++)
+            {
+                // mat4 * vec4(vertex, 1): columns scaled by the components, summed left to right (glm)
+                for (int k = 0; k < 3; k++)
+                {
+                    float const w = m.m[0 * 4 + k] * corners[v][0] + m.m[1 * 4 + k] * corners[v][1] + m.m[2 * 4 + k] * corners[v][2] +
+                                    m.m[3 * 4 + k] * 1.0f;
+                    mn[k] = std::fmin(w, mn[k]);
+                    mx[k] = std::fmax(w, mx[k]);
+                }
+            }
+        }
+    }
+    if (mn[0] > mx[0] || mn[1] > mx[1] || mn[2] > mx[2])
+    {
+        return 0; // not a single valid vertex
+    }
+    szg_aabb_create(mn, mx, out);
+    return 1;
+}
+
 // tickMeshInstance, scene.cpp:461-523
 void szg_tick_mesh_instance(uint32_t animation, const szg_transform* originals, szg_transform* transforms, uint32_t count,
                             double time_elapsed_seconds, double delta_time_seconds, szg_mat4* out_models,

@@ -299,3 +299,32 @@ def test_transform_matrix_and_mesh_instance_tick():
             want = np_translate(tr) @ np_orientate4(eu) @ np.diag(list(originals[i].scale) + [1.0])
             assert close(models[i].to_numpy(), want, 1e-5)
             assert close(mits[i].to_numpy(), np.linalg.inv(want).T, 1e-4)
+
+
+def test_calculate_shadow_bounds_of_the_default_scene():
+    """Scene::calculateShadowBounds (scene.cpp:95-148) on the editor's start-up scene (editor.cpp:500-545): two cubes of scale
+    5 at (0, -8, +-6) and the 20 x 20 floor at y = -1 -> x in [-20, 20], y in [-13, -1], z in [-20, 20]."""
+    cube, plane = abi.AABB(), abi.AABB()
+    lib().szg_aabb_create(abi.f3(-1, -1, -1), abi.f3(1, 1, 1), C.byref(cube))
+    lib().szg_aabb_create(abi.f3(-1, 0, -1), abi.f3(1, 0, 1), C.byref(plane))
+
+    def transforms(*items):
+        arr = (abi.Transform * len(items))()
+        for t, (tr, sc) in zip(arr, items):
+            t.translation[:], t.eulerAnglesRadians[:], t.scale[:] = list(tr), [0.0, 0.0, 0.0], list(sc)
+        return arr
+
+    t1, t2, t3 = transforms(((0, -8, 6), (5, 5, 5))), transforms(((0, -8, -6), (5, 5, 5))), transforms(((0, -1, 0), (20, 1, 20)))
+    casters = (abi.ShadowCaster * 3)(abi.ShadowCaster(cube, t1, 1, 1, 1, 0), abi.ShadowCaster(cube, t2, 1, 1, 1, 0),
+                                     abi.ShadowCaster(plane, t3, 1, 1, 1, 0))
+    out = abi.AABB()
+    assert lib().szg_calculate_shadow_bounds(casters, 3, C.byref(out)) == 1
+    assert np.allclose(list(out.center), [0.0, -7.0, 0.0]) and np.allclose(list(out.half_extent), [20.0, 6.0, 20.0])
+    # a caster that is hidden or casts no shadow does not count; none at all leaves the bounds empty
+    casters[2].casts_shadow = 0
+    assert lib().szg_calculate_shadow_bounds(casters, 3, C.byref(out)) == 1
+    assert np.allclose(list(out.center), [0.0, -8.0, 0.0]) and np.allclose(list(out.half_extent), [5.0, 5.0, 11.0])
+    for c in casters:
+        c.render = 0
+    assert lib().szg_calculate_shadow_bounds(casters, 3, C.byref(out)) == 0
+    assert list(out.center) == [0.0, 0.0, 0.0] and list(out.half_extent) == [0.0, 0.0, 0.0]
