@@ -36,3 +36,14 @@ def test_bench_contract_and_two_rank_rehearsal():
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["parallelism"] == "rowtile2+gather"
     assert two["image_checksum"] == one["image_checksum"]
     assert abs(two["config"]["geometry_fraction"] - one["config"]["geometry_fraction"]) < 1e-12
+
+
+def test_example_frame_loop_runs():
+    """examples/frame_loop.py: scene tick -> shadow bounds -> baked atmosphere -> mesh raster -> lights -> atmosphere ->
+    OETF for a few animated frames; the image must be finite, opaque and not black."""
+    r = subprocess.run([sys.executable, "examples/frame_loop.py", "--frames", "4", "--width", "320", "--height", "180",
+                        "--shadow-map", "512"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "ms per frame" in r.stdout
+    value = float(r.stdout.split("mean display value")[1].split()[0])
+    assert 0.02 < value < 0.98
