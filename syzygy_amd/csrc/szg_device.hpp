@@ -104,6 +104,19 @@ SZG_DEV float divR(float a, float b, float y)
     return __builtin_copysignf(q, q0); // a zero quotient keeps the sign IEEE division gives it
 }
 SZG_DEV float divN(float a, float b) { return divR(a, b, rcpN(b)); }
+// divR without the sign fix of a zero quotient (one v_bfi less). Used where a quotient of zero is consumed sign-blind or
+// cannot be negative — every divRX site: exp(+-0) = 1 (densities), 1 - (+-0) (ozone tent), bias + q * scale with bias > 0
+// (both LUT coordinates), mu only as -r*mu + sqrt(...) >= 0 and mu*mu (LUT tap), (mu_sun - c) - e0 with e0 != 0 (sun
+// smoothstep), non-negative numerators over positive denominators (rho / H, Rp / r, distance * (i + .5) / 500), whose zero
+// quotient comes out +0 on its own.
+SZG_DEV float divR0(float a, float b, float y)
+{
+    float const q0 = a * y;
+    float r = __builtin_fmaf(-b, q0, a);
+    float q = __builtin_fmaf(r, y, q0);
+    r = __builtin_fmaf(-b, q, a);
+    return __builtin_fmaf(r, y, q);
+}
 // sqrt(x) for x == 0 or x in [2^-96, FLT_MAX] (NaN -> NaN): v_rsq_f32 seed, one Newton step on the exact fma residual.
 // Bit-identical to sqrtf for EVERY binary32 value of that domain (tools/verify_sqrt.hip, exhaustive on MI355X).
 // The max() only matters for x == 0: rsq stays finite, so 0 * y = 0 and the correction is fma(0, h, 0) = 0.
@@ -118,7 +131,7 @@ SZG_DEV float sqrtN(float x)
 template <bool LEAN> SZG_DEV float sqrtX(float x) { return LEAN ? sqrtN(x) : sqrtf(x); }
 template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
 template <bool LEAN> SZG_DEV float divX(float a, float b) { return LEAN ? divN(a, b) : a / b; }
-template <bool LEAN> SZG_DEV float divRX(float a, float b, float y) { return LEAN ? divR(a, b, y) : a / b; }
+template <bool LEAN> SZG_DEV float divRX(float a, float b, float y) { return LEAN ? divR0(a, b, y) : a / b; }
 SZG_DEV float xorSign(float x, unsigned signMask)
 {
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) ^ signMask);
