@@ -91,3 +91,21 @@ def test_null_arguments_are_rejected():
     assert lib().szg_compose_rowtiles(None, None, 0, 1, 1, None, 0, 0) == -1
     lib().szg_skyview_destroy(None)
     lib().szg_deferred_destroy(None)
+    # every record entry point rejects a NULL pipeline before touching a device, and says why
+    rect = abi.Rect(0, 0, 8, 8)
+    assert lib().szg_deferred_record_gbuffer_raster(None, None, rect, None, None, 0, None, None, 0) == -1
+    assert b"szg_deferred_record_gbuffer_raster" in lib().szg_last_error()
+    assert lib().szg_deferred_record_shadow_raster(None, None, None, 0, None, 0, None, 0) == -1
+    assert lib().szg_deferred_record_draw_commands_meshes(None, None, rect, None, None, 0, None, 0, None, 0, 0, None, None, 0) == -1
+    assert lib().szg_deferred_record_lights(None, None, rect, None, None, 0, None, 0, None, 0, 0, None) == -1
+    assert lib().szg_skyview_record_transmittance(None, None, 0, None) == -1
+    assert lib().szg_record_oetf(None, None, 8, 8, abi.SZG_OETF_SRGB) == -1
+    assert b"szg_record_oetf" in lib().szg_last_error()
+
+
+def test_host_raster_helpers_need_no_device():
+    """szg_transform_matrix / szg_tick_mesh_instance / szg_calculate_shadow_bounds are CPU-only (include/szg/host.h)."""
+    m = abi.Mat4()
+    lib().szg_transform_matrix(abi.f3(1, 2, 3), abi.f3(0, 0, 0), abi.f3(2, 2, 2), C.byref(m))
+    a = m.to_numpy()
+    assert a[0, 0] == 2.0 and a[0, 3] == 1.0 and a[1, 3] == 2.0 and a[2, 3] == 3.0 and a[3, 3] == 1.0
