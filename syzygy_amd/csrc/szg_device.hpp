@@ -130,7 +130,8 @@ SZG_DEV float sqrtN(float x)
 }
 template <bool LEAN> SZG_DEV float sqrtX(float x) { return LEAN ? sqrtN(x) : sqrtf(x); }
 template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
-template <bool LEAN> SZG_DEV float divX(float a, float b) { return LEAN ? divN(a, b) : a / b; }
+// (quotients of the divX sites — the two segment cosines and the smoothstep argument — are consumed sign-blind too)
+template <bool LEAN> SZG_DEV float divX(float a, float b) { return LEAN ? divR0(a, b, rcpN(b)) : a / b; }
 template <bool LEAN> SZG_DEV float divRX(float a, float b, float y) { return LEAN ? divR0(a, b, y) : a / b; }
 SZG_DEV float xorSign(float x, unsigned signMask)
 {
@@ -484,10 +485,13 @@ template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const 
     float const fv = floorf(v);
     p.b = v - fv;
     p.omb = 1.0f - p.b;
-    int j0 = (int)fv;
-    int j1 = j0 + 1;
-    j0 = min(max(j0, 0), L.height - 1);
-    j1 = min(max(j1, 0), L.height - 1);
+    // clamp((int)fv, 0, H-1) and clamp((int)fv + 1, 0, H-1) with the clamp done in float by v_med3_f32 (one instruction
+    // instead of two integer ones per index): the same indices for every finite fv (integer-valued; beyond 2^24
+    // fv + 1 == fv and both land on the same edge, as the saturating conversion does). For a NaN fv the weights are NaN
+    // and so is the result, whichever texels are fetched.
+    float const hm1 = L.fheight - 1.0f;
+    int const j0 = (int)__builtin_amdgcn_fmed3f(fv, 0.0f, hm1);
+    int const j1 = (int)__builtin_amdgcn_fmed3f(fv + 1.0f, 0.0f, hm1);
     p.row0 = (unsigned)(j0 * L.width);
     p.row1 = (unsigned)(j1 * L.width);
     return p;
@@ -500,10 +504,9 @@ template <bool LEAN = false> SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, 
     float const u = s * L.fwidth - 0.5f;
     float const fu = floorf(u);
     float const al = u - fu;
-    int i0 = (int)fu;
-    int i1 = i0 + 1;
-    i0 = min(max(i0, 0), L.width - 1);
-    i1 = min(max(i1, 0), L.width - 1);
+    float const wm1 = L.fwidth - 1.0f;
+    int const i0 = (int)__builtin_amdgcn_fmed3f(fu, 0.0f, wm1); // see radiusPart
+    int const i1 = (int)__builtin_amdgcn_fmed3f(fu + 1.0f, 0.0f, wm1);
     // only .rgb is consumed (common.glinl:111, :142): 12-byte loads keep 16 VGPRs per step out of flight
     const char* const base = reinterpret_cast<const char*>(L.texels);
     Rgb const t00 = *reinterpret_cast<const Rgb*>(base + ((p.row0 + (unsigned)i0) << 4));
