@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void k_transmittance(const szg_atmosphere_pack
     float const ndt = -fabsf(dt);
     // lean exact ops (szg_device.hpp) when the atmosphere block and this ray are in their domain; the flag is
     // wave-uniform so that the loop body exists once per wave
-    bool const lean = __all(a.lean && inRange(radius, 0.9f * a.planetRadius, 0x1p30f) && inRange(distance, 0.0f, 0x1p30f));
+    // smallest squared radius along the ray: at the closest approach when the ray points downwards, else at its origin
+    float const rmin2 = mu < 0.0f ? radius * radius * (1.0f - mu * mu) : radius * radius;
+    bool const lean = __all(a.lean && rmin2 >= a.leanFloor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(distance, 0.0f, 0x1p30f));
     V3 const T = lean ? transmittanceProduct<true>(a, origin, direction, distance, ndt, sub)
                       : transmittanceProduct<false>(a, origin, direction, distance, ndt, sub);
     if (inRangeTexel && sub == T_LANES - 1)

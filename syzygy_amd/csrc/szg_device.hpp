@@ -297,7 +297,22 @@ struct Atm
     // refined reciprocals for divR (valid when `lean`)
     float rcpH, rcpDsR, rcpDsM, rcp15;
     bool lean; // leanAtmosphere(): every atmosphere-level precondition of the lean ops holds
+    // Squared radius floor of the lean paths: >= 0.9 Rp (the x_mu denominator) and >= Rp - 80 min(Hr, Hm), so that both
+    // densities exp(-altitude / H) stay finite (<= e^80) wherever a lean path evaluates them.
+    float leanFloor2;
+    // Zero coefficient vectors (Earth defaults: Rayleigh absorption and ozone scattering are 0, scene.cpp:62-70). With
+    // finite densities their terms are exactly +0, and acc + (+0) == acc for every acc but -0, which a sum of
+    // products of sign-clear coefficients and non-negative densities cannot be: the lean paths skip those terms.
+    bool zeroAbsorptionRayleigh, zeroScatteringOzone;
 };
+SZG_DEV bool plusZero3(V3 v)
+{
+    return (__builtin_bit_cast(unsigned, v.x) | __builtin_bit_cast(unsigned, v.y) | __builtin_bit_cast(unsigned, v.z)) == 0u;
+}
+SZG_DEV bool signClear3(V3 v) // no component negative, -0 or NaN-with-sign; (+NaN passes and poisons every sum alike)
+{
+    return ((__builtin_bit_cast(unsigned, v.x) | __builtin_bit_cast(unsigned, v.y) | __builtin_bit_cast(unsigned, v.z)) >> 31) == 0u;
+}
 SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
 {
     Atm a;
@@ -322,6 +337,11 @@ SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
     a.lean = inRange(a.planetRadius, lo, hi) && inRange(a.atmosphereRadius, lo, hi) && inRange(a.H, lo, hi) &&
              inRange(a.densityScaleRayleigh, lo, hi) && inRange(a.densityScaleMie, lo, hi) &&
              (a.H - a.atmosphereRadius + 0.9f * a.planetRadius >= 0x1p-20f);
+    float const rFloor = fmaxf(0.9f * a.planetRadius, a.planetRadius - 80.0f * fminf(a.densityScaleRayleigh, a.densityScaleMie));
+    a.leanFloor2 = rFloor * rFloor;
+    bool const signs = signClear3(a.scatteringRayleigh) && signClear3(a.scatteringMie);
+    a.zeroAbsorptionRayleigh = signs && plusZero3(a.absorptionRayleigh);
+    a.zeroScatteringOzone = signs && signClear3(a.absorptionRayleigh) && plusZero3(a.scatteringOzone);
     a.rcpH = rcpN(a.lean ? a.H : 1.0f);
     a.rcpDsR = rcpN(a.lean ? a.densityScaleRayleigh : 1.0f);
     a.rcpDsM = rcpN(a.lean ? a.densityScaleMie : 1.0f);
@@ -350,7 +370,19 @@ template <bool LEAN = false> SZG_DEV Extinction sampleExtinction(const Atm& a, f
     Extinction e;
     e.scatteringRayleigh = scatteringRayleigh;
     e.scatteringMie = scatteringMie;
-    e.extinction = scatteringRayleigh + absorptionRayleigh + scatteringMie + absorptionMie + scatteringOzone + absorptionOzone;
+    if (LEAN && a.zeroAbsorptionRayleigh && a.zeroScatteringOzone)
+    {
+        // + absorptionRayleigh, + absorptionMie (= absorptionRayleigh coefficient, Q1) and + scatteringOzone add exact +0
+        e.extinction = (scatteringRayleigh + scatteringMie) + absorptionOzone;
+    }
+    else if (LEAN && a.zeroAbsorptionRayleigh)
+    {
+        e.extinction = ((scatteringRayleigh + scatteringMie) + scatteringOzone) + absorptionOzone;
+    }
+    else
+    {
+        e.extinction = scatteringRayleigh + absorptionRayleigh + scatteringMie + absorptionMie + scatteringOzone + absorptionOzone;
+    }
     return e;
 }
 
@@ -689,8 +721,7 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     float const L2 = sampleDistance * sampleDistance + m.two_r_mu * sampleDistance + m.r2;
     float const tStar = -m.r_mu;
     float const rmin2 = (tStar > 0.0f && tStar < sampleDistance) ? m.r2 * (1.0f - mu * mu) : fminf(m.r2, L2);
-    float const floor2 = (0.9f * a.planetRadius) * (0.9f * a.planetRadius);
-    bool const lean = a.lean && rmin2 >= floor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(sampleDistance, 0.0f, 0x1p30f) &&
+    bool const lean = a.lean && rmin2 >= a.leanFloor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(sampleDistance, 0.0f, 0x1p30f) &&
                       m.sin_sunRadius >= 0x1p-30f;
     // wave-uniform choice: one lane outside the domain sends its whole wave down the generic path
     if (__all(lean))

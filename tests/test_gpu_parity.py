@@ -382,7 +382,34 @@ def _tiny_density_scale(a):
     a.altitudeDecayMieMegameters = 2.0 ** -34  # outside [2^-30, 2^30]
 
 
-@pytest.mark.parametrize("edit", [_thin_shell, _tiny_density_scale])
+def _absorbing_rayleigh(a):  # the Earth defaults have zero Rayleigh absorption and zero ozone scattering; the lean
+    a.absorptionRayleighPerMegameter[:] = [0.7, 1.3, 2.9]  # paths drop those exact-zero terms (szg_device.hpp Atm)
+
+
+def _scattering_ozone(a):
+    a.scatteringOzonePerMegameter[:] = [0.3, 0.2, 0.9]
+
+
+def _absorbing_and_scattering(a):
+    _absorbing_rayleigh(a)
+    _scattering_ozone(a)
+
+
+def _one_nonzero_component(a):
+    a.absorptionRayleighPerMegameter[:] = [0.0, 0.0, 0.5]
+
+
+def _negative_zero_coefficient(a):  # -0 clears the sign test: the full sum must be evaluated
+    a.scatteringRayleighPerMegameter[0] = -0.0
+    a.scatteringMiePerMegameter[2] = -0.0
+
+
+def _camera_deep_underground_lean_floor(a):  # shell so thick that Rp - 80 H is the active floor, not 0.9 Rp
+    a.altitudeDecayMieMegameters = 0.0004
+
+
+@pytest.mark.parametrize("edit", [_thin_shell, _tiny_density_scale, _absorbing_rayleigh, _scattering_ozone, _absorbing_and_scattering,
+                                  _one_nonzero_component, _negative_zero_coefficient, _camera_deep_underground_lean_floor])
 def test_generic_path_unusual_atmospheres(gpu, edit):
     inp = util.Inputs(128, 72, elevation_degrees=30.0, spots=6, atmosphere_edit=edit)
     got, got_q = render_gpu(gpu, inp, lut=((128, 32), (128, 64)))
