@@ -58,9 +58,10 @@ SZG_FP_FN float szg_div_moderate(float n, float d)
  * the GPU kernels. */
 
 /* exp(x), natural. */
-SZG_FP_FN float szg_expf(float x)
+/* exp(x) for x that is not NaN (a NaN argument gives exp(-104)): szg_expf without its last select. */
+SZG_FP_FN float szg_expf_notnan(float x)
 {
-    float const xc = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f); /* NaN -> -104, patched below */
+    float const xc = __builtin_fminf(__builtin_fmaxf(x, -104.0f), 89.0f);
     float const q = __builtin_rintf(xc * 1.442695040888963407359924681001892137426645954152985934135449406931f);
     float s = __builtin_fmaf(q, -0.693145751953125f, xc);
     s = __builtin_fmaf(q, -1.428606765330187045e-06f, s);
@@ -73,7 +74,11 @@ SZG_FP_FN float szg_expf(float x)
     u = __builtin_fmaf(s * s, u, s) + 1.0f;
     int const qi = (int)q;
     int const q1 = qi >> 1;
-    float const r = (u * szg_pow2i(q1)) * szg_pow2i(qi - q1);
+    return (u * szg_pow2i(q1)) * szg_pow2i(qi - q1);
+}
+SZG_FP_FN float szg_expf(float x)
+{
+    float const r = szg_expf_notnan(x);
     return (x == x) ? r : x;
 }
 

@@ -40,9 +40,9 @@ template <bool LEAN> SZG_DEV V3 transmittanceProduct(const Atm& a, V3 origin, V3
         float const altitude = sqrtX<LEAN>(dot(position, position)) - a.planetRadius;
         Extinction const e = sampleExtinction<LEAN>(a, altitude);
         bool const valid = i < T_STEPS;
-        float const fx = valid ? szg_expf(ndt * e.extinction.x) : 1.0f;
-        float const fy = valid ? szg_expf(ndt * e.extinction.y) : 1.0f;
-        float const fz = valid ? szg_expf(ndt * e.extinction.z) : 1.0f;
+        float const fx = valid ? expX<LEAN>(ndt * e.extinction.x) : 1.0f;
+        float const fy = valid ? expX<LEAN>(ndt * e.extinction.y) : 1.0f;
+        float const fz = valid ? expX<LEAN>(ndt * e.extinction.z) : 1.0f;
         // Ordered product along the 8 lanes of the group with DPP (no LDS): position 0 takes the running
         // product from position 7 (row_shl:7), then position j takes position j-1's value (row_shr:1) and
         // multiplies its own factor. After 8 steps position 7 holds (((P * f0) * f1) ... * f7).

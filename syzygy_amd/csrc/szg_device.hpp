@@ -131,6 +131,7 @@ SZG_DEV float sqrtN(float x)
 template <bool LEAN> SZG_DEV float sqrtX(float x) { return LEAN ? sqrtN(x) : sqrtf(x); }
 template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
 // (quotients of the divX sites — the two segment cosines and the smoothstep argument — are consumed sign-blind too)
+template <bool LEAN> SZG_DEV float expX(float x) { return LEAN ? szg_expf_notnan(x) : szg_expf(x); }
 template <bool LEAN> SZG_DEV float divX(float a, float b) { return LEAN ? divR0(a, b, rcpN(b)) : a / b; }
 template <bool LEAN> SZG_DEV float divRX(float a, float b, float y) { return LEAN ? divR0(a, b, y) : a / b; }
 SZG_DEV float xorSign(float x, unsigned signMask)
@@ -337,6 +338,15 @@ SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
     a.lean = inRange(a.planetRadius, lo, hi) && inRange(a.atmosphereRadius, lo, hi) && inRange(a.H, lo, hi) &&
              inRange(a.densityScaleRayleigh, lo, hi) && inRange(a.densityScaleMie, lo, hi) &&
              (a.H - a.atmosphereRadius + 0.9f * a.planetRadius >= 0x1p-20f);
+    // coefficients finite and of moderate magnitude: no NaN / inf can enter the extinction sum on a lean path
+    // (expX<true> relies on that)
+    V3 const* const coefficients[5] = {&a.scatteringRayleigh, &a.absorptionRayleigh, &a.scatteringMie, &a.scatteringOzone, &a.absorptionOzone};
+#pragma unroll
+    for (int i = 0; i < 5; i++)
+    {
+        a.lean = a.lean && inRange(fabsf(coefficients[i]->x), 0.0f, hi) && inRange(fabsf(coefficients[i]->y), 0.0f, hi) &&
+                 inRange(fabsf(coefficients[i]->z), 0.0f, hi);
+    }
     float const rFloor = fmaxf(0.9f * a.planetRadius, a.planetRadius - 80.0f * fminf(a.densityScaleRayleigh, a.densityScaleMie));
     a.leanFloor2 = rFloor * rFloor;
     bool const signs = signClear3(a.scatteringRayleigh) && signClear3(a.scatteringMie);
@@ -358,10 +368,11 @@ struct Extinction
 };
 template <bool LEAN = false> SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude)
 {
-    float const densityRayleigh = szg_expf(divRX<LEAN>(-altitude, a.densityScaleRayleigh, a.rcpDsR));
+    // (the lean paths never see a NaN altitude: every radius along the ray is finite and above the lean floor)
+    float const densityRayleigh = expX<LEAN>(divRX<LEAN>(-altitude, a.densityScaleRayleigh, a.rcpDsR));
     V3 const scatteringRayleigh = a.scatteringRayleigh * densityRayleigh;
     V3 const absorptionRayleigh = a.absorptionRayleigh * densityRayleigh;
-    float const densityMie = szg_expf(divRX<LEAN>(-altitude, a.densityScaleMie, a.rcpDsM));
+    float const densityMie = expX<LEAN>(divRX<LEAN>(-altitude, a.densityScaleMie, a.rcpDsM));
     V3 const scatteringMie = a.scatteringMie * densityMie;
     V3 const absorptionMie = a.absorptionRayleigh * densityMie;
     float const densityOzone = fmaxf(0.0f, 1.0f - divRX<LEAN>(fabsf(altitude * 1000.0f - 25.0f), 15.0f, a.rcp15));

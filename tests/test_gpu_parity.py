@@ -404,12 +404,21 @@ def _negative_zero_coefficient(a):  # -0 clears the sign test: the full sum must
     a.scatteringMiePerMegameter[2] = -0.0
 
 
+def _nan_coefficient(a):  # a NaN in the block poisons the frame identically on both sides (generic path)
+    a.absorptionOzonePerMegameter[1] = float("nan")
+
+
+def _infinite_coefficient(a):
+    a.scatteringMiePerMegameter[0] = float("inf")
+
+
 def _camera_deep_underground_lean_floor(a):  # shell so thick that Rp - 80 H is the active floor, not 0.9 Rp
     a.altitudeDecayMieMegameters = 0.0004
 
 
 @pytest.mark.parametrize("edit", [_thin_shell, _tiny_density_scale, _absorbing_rayleigh, _scattering_ozone, _absorbing_and_scattering,
-                                  _one_nonzero_component, _negative_zero_coefficient, _camera_deep_underground_lean_floor])
+                                  _one_nonzero_component, _negative_zero_coefficient, _nan_coefficient, _infinite_coefficient,
+                                  _camera_deep_underground_lean_floor])
 def test_generic_path_unusual_atmospheres(gpu, edit):
     inp = util.Inputs(128, 72, elevation_degrees=30.0, spots=6, atmosphere_edit=edit)
     got, got_q = render_gpu(gpu, inp, lut=((128, 32), (128, 64)))
