@@ -305,6 +305,7 @@ struct Atm
     // finite densities their terms are exactly +0, and acc + (+0) == acc for every acc but -0, which a sum of
     // products of sign-clear coefficients and non-negative densities cannot be: the lean paths skip those terms.
     bool zeroAbsorptionRayleigh, zeroScatteringOzone;
+    bool signClearCoefficients; // Rayleigh / Mie scattering and Rayleigh absorption carry no sign bit: partial sums are never -0
 };
 SZG_DEV bool plusZero3(V3 v)
 {
@@ -350,6 +351,7 @@ SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
     float const rFloor = fmaxf(0.9f * a.planetRadius, a.planetRadius - 80.0f * fminf(a.densityScaleRayleigh, a.densityScaleMie));
     a.leanFloor2 = rFloor * rFloor;
     bool const signs = signClear3(a.scatteringRayleigh) && signClear3(a.scatteringMie);
+    a.signClearCoefficients = signs && signClear3(a.absorptionRayleigh);
     a.zeroAbsorptionRayleigh = signs && plusZero3(a.absorptionRayleigh);
     a.zeroScatteringOzone = signs && signClear3(a.absorptionRayleigh) && plusZero3(a.scatteringOzone);
     a.rcpH = rcpN(a.lean ? a.H : 1.0f);
@@ -375,12 +377,23 @@ template <bool LEAN = false> SZG_DEV Extinction sampleExtinction(const Atm& a, f
     float const densityMie = expX<LEAN>(divRX<LEAN>(-altitude, a.densityScaleMie, a.rcpDsM));
     V3 const scatteringMie = a.scatteringMie * densityMie;
     V3 const absorptionMie = a.absorptionRayleigh * densityMie;
-    float const densityOzone = fmaxf(0.0f, 1.0f - divRX<LEAN>(fabsf(altitude * 1000.0f - 25.0f), 15.0f, a.rcp15));
-    V3 const scatteringOzone = a.scatteringOzone * densityOzone;
-    V3 const absorptionOzone = a.absorptionOzone * densityOzone;
     Extinction e;
     e.scatteringRayleigh = scatteringRayleigh;
     e.scatteringMie = scatteringMie;
+    float const ozoneOffset = fabsf(altitude * 1000.0f - 25.0f);
+    // Outside the ozone tent (|h - 25 km| >= 15 km) the density is max(0, 1 - q) with q >= 1, i.e. +0, and both ozone
+    // products are +-0: adding them to a partial sum that is not -0 (sign-clear coefficients) changes nothing. When that holds for the whole wave (aerial-perspective marches
+    // near the ground, high-altitude samples) the tent, its division and the two terms are skipped.
+    bool const noOzone = LEAN && a.signClearCoefficients && __all(ozoneOffset >= 15.0f);
+    if (noOzone)
+    {
+        e.extinction = a.zeroAbsorptionRayleigh ? (scatteringRayleigh + scatteringMie)
+                                                : (((scatteringRayleigh + absorptionRayleigh) + scatteringMie) + absorptionMie);
+        return e;
+    }
+    float const densityOzone = fmaxf(0.0f, 1.0f - divRX<LEAN>(ozoneOffset, 15.0f, a.rcp15));
+    V3 const scatteringOzone = a.scatteringOzone * densityOzone;
+    V3 const absorptionOzone = a.absorptionOzone * densityOzone;
     if (LEAN && a.zeroAbsorptionRayleigh && a.zeroScatteringOzone)
     {
         // + absorptionRayleigh, + absorptionMie (= absorptionRayleigh coefficient, Q1) and + scatteringOzone add exact +0
@@ -672,9 +685,20 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         V3 const T_atm = sampleT_at<LEAN>(L, a, pStep, s_musun);
         float const e0 = -sin_hz * m.sin_sunRadius;
         float const e1 = sin_hz * m.sin_sunRadius;
-        float const ss = clampf(divX<LEAN>((s_musun - cos_hz * m.cos_sunRadius) - e0, e1 - e0), 0.0f, 1.0f);
-        float const angularFactor = ss * ss * (3.0f - 2.0f * ss);
-        V3 const T_sun = T_atm * angularFactor;
+        float const ssNum = (s_musun - cos_hz * m.cos_sunRadius) - e0, ssDen = e1 - e0;
+        V3 T_sun;
+        if (LEAN && __all(ssNum >= ssDen && ssDen > 0.0f))
+        {
+            // the sun disc is entirely above the sample's horizon for the whole wave: num / den >= 1 clamps to 1,
+            // smoothstep(1) = 1 * 1 * (3 - 2) = 1 and T_atm * 1 = T_atm, all exactly
+            T_sun = T_atm;
+        }
+        else
+        {
+            float const ss = clampf(divX<LEAN>(ssNum, ssDen), 0.0f, 1.0f);
+            float const angularFactor = ss * ss * (3.0f - 2.0f * ss);
+            T_sun = T_atm * angularFactor;
+        }
 
         Extinction const ex = sampleExtinction<LEAN>(a, altitude);
 
