@@ -703,9 +703,14 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         Extinction const ex = sampleExtinction<LEAN>(a, altitude);
 
         // sampleTransmittanceLUT_RayMarchStep, common.glinl:336-361
-        V3 const T_end = sampleT_at<LEAN>(L, a, pStep, xorSign(s_mu, m.up ? 0u : 0x80000000u));
-        V3 const ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
-        V3 const T_begin = (t < 0.0000001f) ? splat(1.0f) : ratio;
+        // (t < 1e-7 -> 1, common.glinl:338-341: true for the whole wave at step 0, where the tap and the quotients are skipped)
+        V3 T_begin = splat(1.0f);
+        if (!__all(t < 0.0000001f))
+        {
+            V3 const T_end = sampleT_at<LEAN>(L, a, pStep, xorSign(s_mu, m.up ? 0u : 0x80000000u));
+            V3 const ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
+            T_begin = (t < 0.0000001f) ? splat(1.0f) : ratio;
+        }
 
         V3 const phaseTimesScattering = ex.scatteringRayleigh * m.pR + ex.scatteringMie * m.pM;
 
