@@ -154,12 +154,23 @@ def main():
     spot_arg = spots if SPOTS else None
     pending = []  # (gathered buffer, work) of the previous frame's tile gather
 
+    # rank 0 scatters the gathered tiles into the frame on a side stream: an HBM-bound copy that runs under the next
+    # frame's VALU-bound passes instead of in front of them (rank 0 is the slowest rank otherwise)
+    side = torch.cuda.Stream() if (tiled and rank == 0) else None
+    compose_done = {}
+
     def finish_gather():
         while pending:
             buf, work = pending.pop(0)
             work.wait()  # the compute stream waits for the collective; the host does not block
             if rank == 0:
-                rowtile.compose(buf, H, nranks, BLOCK_ROWS, out=composed)
+                arrived = torch.cuda.Event()
+                arrived.record()
+                side.wait_event(arrived)
+                rowtile.compose(buf, H, nranks, BLOCK_ROWS, out=composed, stream=side.cuda_stream)
+                done = torch.cuda.Event()
+                done.record(side)
+                compose_done[buf.data_ptr()] = done
 
     def frame(k, events=None):
         e = events
@@ -198,6 +209,9 @@ def main():
         if tiled:
             # the gather of frame k-1 has had a whole frame of compute to finish: compose it now, then start ours
             finish_gather()
+            if rank == 0 and gathered[k % 2].data_ptr() in compose_done:
+                # this gather buffer was last read by the compose of frame k-2 on the side stream
+                torch.cuda.current_stream().wait_event(compose_done[gathered[k % 2].data_ptr()])
             buf, work = rowtile.gather_tiles(tgt.color, rank, nranks, gathered=gathered[k % 2] if rank == 0 else None,
                                              async_op=True)
             pending.append((buf, work))
