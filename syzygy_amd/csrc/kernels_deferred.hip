@@ -307,7 +307,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     // (=> lightFalloff = factor * (dist / falloffDistance)^2 with the per-light constants checked by k_light_prep),
     // the half-vector length, and the position magnitude. One lane outside sends the wave down the generic path.
     float const lo = 0x1p-30f, hi = 0x1p30f;
-    bool const lean = __all(L.leanOK != 0u && positionModerate && inRange(fabsf(cw), lo, hi) && inRange(d2, lo, hi) &&
+    bool const lean = waveAll(L.leanOK != 0u && positionModerate && inRange(fabsf(cw), lo, hi) && inRange(d2, lo, hi) &&
                             inRange(hd, 0x1p-40f, 8.0f));
 
     float const ycw = lean ? rcpN(cw) : 0.0f;

@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void k_transmittance(const szg_atmosphere_pack
     // wave-uniform so that the loop body exists once per wave
     // smallest squared radius along the ray: at the closest approach when the ray points downwards, else at its origin
     float const rmin2 = mu < 0.0f ? radius * radius * (1.0f - mu * mu) : radius * radius;
-    bool const lean = __all(a.lean && rmin2 >= a.leanFloor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(distance, 0.0f, 0x1p30f));
+    bool const lean = waveAll(a.lean && rmin2 >= a.leanFloor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(distance, 0.0f, 0x1p30f));
     V3 const T = lean ? transmittanceProduct<true>(a, origin, direction, distance, ndt, sub)
                       : transmittanceProduct<false>(a, origin, direction, distance, ndt, sub);
     if (inRangeTexel && sub == T_LANES - 1)

@@ -139,6 +139,9 @@ SZG_DEV float xorSign(float x, unsigned signMask)
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) ^ signMask);
 }
 SZG_DEV bool inRange(float x, float lo, float hi) { return x >= lo && x <= hi; } // false for NaN
+// true when `c` holds on every active lane: one compare into a lane mask and one scalar test (HIP's __all() builds two
+// ballots from an int predicate, ~15 instructions per use)
+SZG_DEV bool waveAll(bool c) { return __builtin_amdgcn_ballot_w64(!c) == 0ull; }
 
 // column-major 4x4 times (x, y, z, w), rows summed left to right
 struct M4
@@ -384,7 +387,7 @@ template <bool LEAN = false> SZG_DEV Extinction sampleExtinction(const Atm& a, f
     // Outside the ozone tent (|h - 25 km| >= 15 km) the density is max(0, 1 - q) with q >= 1, i.e. +0, and both ozone
     // products are +-0: adding them to a partial sum that is not -0 (sign-clear coefficients) changes nothing. When that holds for the whole wave (aerial-perspective marches
     // near the ground, high-altitude samples) the tent, its division and the two terms are skipped.
-    bool const noOzone = LEAN && a.signClearCoefficients && __all(ozoneOffset >= 15.0f);
+    bool const noOzone = LEAN && a.signClearCoefficients && waveAll(ozoneOffset >= 15.0f);
     if (noOzone)
     {
         e.extinction = a.zeroAbsorptionRayleigh ? (scatteringRayleigh + scatteringMie)
@@ -687,7 +690,7 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         float const e1 = sin_hz * m.sin_sunRadius;
         float const ssNum = (s_musun - cos_hz * m.cos_sunRadius) - e0, ssDen = e1 - e0;
         V3 T_sun;
-        if (LEAN && __all(ssNum >= ssDen && ssDen > 0.0f))
+        if (LEAN && waveAll(ssNum >= ssDen && ssDen > 0.0f))
         {
             // the sun disc is entirely above the sample's horizon for the whole wave: num / den >= 1 clamps to 1,
             // smoothstep(1) = 1 * 1 * (3 - 2) = 1 and T_atm * 1 = T_atm, all exactly
@@ -705,7 +708,7 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         // sampleTransmittanceLUT_RayMarchStep, common.glinl:336-361
         // (t < 1e-7 -> 1, common.glinl:338-341: true for the whole wave at step 0, where the tap and the quotients are skipped)
         V3 T_begin = splat(1.0f);
-        if (!__all(t < 0.0000001f))
+        if (!waveAll(t < 0.0000001f))
         {
             V3 const T_end = sampleT_at<LEAN>(L, a, pStep, xorSign(s_mu, m.up ? 0u : 0x80000000u));
             V3 const ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
@@ -764,7 +767,7 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     bool const lean = a.lean && rmin2 >= a.leanFloor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(sampleDistance, 0.0f, 0x1p30f) &&
                       m.sin_sunRadius >= 0x1p-30f;
     // wave-uniform choice: one lane outside the domain sends its whole wave down the generic path
-    if (__all(lean))
+    if (waveAll(lean))
     {
         return marchLoop<true>(L, a, m);
     }
