@@ -109,7 +109,28 @@ __global__ __launch_bounds__(256) void k_transmittance(const szg_atmosphere_pack
                       : transmittanceProduct<false>(a, origin, direction, distance, ndt, sub);
     if (inRangeTexel && sub == T_LANES - 1)
     {
-        lut[id] = hit ? make_float4(T.x, T.y, T.z, 1.0f) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        float4 const texel = hit ? make_float4(T.x, T.y, T.z, 1.0f) : make_float4(1.0f, 1.0f, 1.0f, 1.0f);
+        lut[id] = texel;
+        if (!tlutTexelModerate(texel.x, texel.y, texel.z))
+        {
+            atomicOr(reinterpret_cast<unsigned*>(lut + (size_t)W * (size_t)H), 1u); // status dword (szg_launch.hpp)
+        }
+    }
+}
+
+// Status dword of a transmittance LUT whose texels were written by someone else (uploaded by the caller).
+__global__ __launch_bounds__(256) void k_lut_range(float4* __restrict__ lut, unsigned n)
+{
+    unsigned const id = blockIdx.x * 256u + threadIdx.x;
+    bool ok = true;
+    if (id < n)
+    {
+        float4 const t = lut[id];
+        ok = tlutTexelModerate(t.x, t.y, t.z);
+    }
+    if (!waveAll(ok) && (threadIdx.x & 63u) == 0u)
+    {
+        atomicOr(reinterpret_cast<unsigned*>(lut + n), 1u);
     }
 }
 
@@ -318,8 +339,25 @@ hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_at
                                 unsigned H)
 {
     unsigned const n = W * H * (unsigned)T_LANES;
+    hipError_t const e = hipMemsetAsync(lut + (size_t)W * H * 4u, 0, 4u, s); // status dword: set by texels out of range
+    if (e != hipSuccess)
+    {
+        return e;
+    }
     hipLaunchKernelGGL(k_transmittance, dim3((n + 255u) / 256u), dim3(256), 0, s, d_atm, atmIndex, reinterpret_cast<float4*>(lut),
                        (int)W, (int)H);
+    return hipGetLastError();
+}
+
+hipError_t launch_lut_range(hipStream_t s, float* lut, unsigned W, unsigned H)
+{
+    unsigned const n = W * H;
+    hipError_t const e = hipMemsetAsync(lut + (size_t)n * 4u, 0, 4u, s);
+    if (e != hipSuccess)
+    {
+        return e;
+    }
+    hipLaunchKernelGGL(k_lut_range, dim3((n + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<float4*>(lut), n);
     return hipGetLastError();
 }
 

@@ -253,7 +253,21 @@ struct szg_skyview
     float* d_aerialTransmittance = nullptr;
     float aerialMaxDistance = 0.0f; // 0 = never recorded
     bool haveTransmittance = false, haveSkyview = false;
+    // false while the caller may have written the transmittance texels through szg_skyview_transmittance_lut():
+    // the next consumer recomputes the block's status dword first (szg_launch.hpp "transmittance LUT block")
+    mutable bool tlutStatusValid = false;
 };
+
+static hipError_t ensure_tlut_status(szg_skyview* p, hipStream_t s)
+{
+    if (p->tlutStatusValid)
+    {
+        return hipSuccess;
+    }
+    hipError_t const e = szg::launch_lut_range(s, p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height);
+    p->tlutStatusValid = (e == hipSuccess);
+    return e;
+}
 
 struct szg_deferred
 {
@@ -355,7 +369,7 @@ int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int de
     p->device = device;
     p->desc = d;
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&p->d_transmittance),
-                             (size_t)d.transmittance_width * d.transmittance_height * 16u);
+                             szg::tlut_block_bytes(d.transmittance_width, d.transmittance_height));
     if (e == hipSuccess)
     {
         e = hipMalloc(reinterpret_cast<void**>(&p->d_skyview), (size_t)d.skyview_width * d.skyview_height * 16u);
@@ -419,6 +433,7 @@ int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out)
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_transmittance_lut: NULL argument");
     }
     *out = make_image(p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, SZG_FORMAT_RGBA32_SFLOAT);
+    p->tlutStatusValid = false; // the caller may write the texels through this view
     return SZG_OK;
 }
 
@@ -442,6 +457,7 @@ int szg_skyview_record_transmittance(szg_skyview_t* p, void* stream, uint32_t at
     SZG_HIP(szg::launch_transmittance(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, p->d_transmittance,
                                       p->desc.transmittance_width, p->desc.transmittance_height));
     p->haveTransmittance = true;
+    p->tlutStatusValid = true;
     return SZG_OK;
 }
 
@@ -458,6 +474,7 @@ int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_skyview_lut_rows: rows [%u, %u) outside the %u-row LUT", row_begin,
                     row_end, p->desc.skyview_height);
     }
+    SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(szg::launch_skyview(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, d_cameras, view_camera_index,
                                 p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
                                 p->desc.skyview_width, p->desc.skyview_height, row_begin, row_end));
@@ -525,6 +542,7 @@ static int record_composite(szg_skyview_t* p, void* stream, const szg_scene_text
         aerial.luminance = p->d_aerialLuminance;
         aerial.maxDistance = p->aerialMaxDistance;
     }
+    SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(szg::launch_composite(static_cast<hipStream_t>(stream), *scene_texture, draw_rect.width, draw_rect.height, t, *gbuffer,
                                   sun, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, d_lights, sun_light_index,
                                   p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
@@ -559,6 +577,7 @@ int szg_skyview_record_multiscatter_lut(szg_skyview_t* p, void* stream, uint32_t
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_multiscatter_lut: NULL argument");
     }
+    SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(szg::launch_multiscatter(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, p->d_transmittance,
                                      p->desc.transmittance_width, p->desc.transmittance_height, p->d_multiscatter,
                                      SZG_MULTISCATTER_DIM));
@@ -587,6 +606,7 @@ int szg_skyview_record_aerial_lut(szg_skyview_t* p, void* stream, uint32_t atmos
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_aerial_lut: max_distance_mm must be in (0, 1e6)");
     }
+    SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(szg::launch_aerial_lut(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, d_cameras, view_camera_index,
                                    p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height,
                                    p->d_aerialLuminance, p->d_aerialTransmittance, SZG_AERIAL_W, SZG_AERIAL_H, SZG_AERIAL_D,

@@ -139,6 +139,7 @@ SZG_DEV float xorSign(float x, unsigned signMask)
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) ^ signMask);
 }
 SZG_DEV bool inRange(float x, float lo, float hi) { return x >= lo && x <= hi; } // false for NaN
+SZG_DEV float divN0(float a, float b) { return divR0(a, b, rcpN(b)); }
 // true when `c` holds on every active lane: one compare into a lane mask and one scalar test (HIP's __all() builds two
 // ballots from an int predicate, ~15 instructions per use)
 SZG_DEV bool waveAll(bool c) { return __builtin_amdgcn_ballot_w64(!c) == 0ull; }
@@ -308,7 +309,11 @@ struct Atm
     // finite densities their terms are exactly +0, and acc + (+0) == acc for every acc but -0, which a sum of
     // products of sign-clear coefficients and non-negative densities cannot be: the lean paths skip those terms.
     bool zeroAbsorptionRayleigh, zeroScatteringOzone;
-    bool signClearCoefficients; // Rayleigh / Mie scattering and Rayleigh absorption carry no sign bit: partial sums are never -0
+    bool signClearCoefficients;
+    // the extinction sum stays in [2^-40, 2^52] for radii in [sqrt(extFloor2), sqrt(extCeil2)] (lean division of the
+    // in-scatter integral): coefficients <= 2^10, densities <= e^27, Rayleigh scattering alone >= 2^-40 at the shell's top
+    bool extModerate;
+    float extFloor2, extCeil2; // Rayleigh / Mie scattering and Rayleigh absorption carry no sign bit: partial sums are never -0
 };
 SZG_DEV bool plusZero3(V3 v)
 {
@@ -357,6 +362,23 @@ SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
     a.signClearCoefficients = signs && signClear3(a.absorptionRayleigh);
     a.zeroAbsorptionRayleigh = signs && plusZero3(a.absorptionRayleigh);
     a.zeroScatteringOzone = signs && signClear3(a.absorptionRayleigh) && plusZero3(a.scatteringOzone);
+    {
+        float const shell = a.atmosphereRadius - a.planetRadius;
+        float const minRayleigh = fminf(fminf(a.scatteringRayleigh.x, a.scatteringRayleigh.y), a.scatteringRayleigh.z);
+        float const thinnest = szg_expf(-1.02f * (shell / a.densityScaleRayleigh)) * 0.5f;
+        bool small = true;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+        {
+            small = small && coefficients[i]->x <= 0x1p10f && coefficients[i]->y <= 0x1p10f && coefficients[i]->z <= 0x1p10f;
+        }
+        a.extModerate = a.lean && a.signClearCoefficients && signClear3(a.scatteringOzone) && signClear3(a.absorptionOzone) && small &&
+                        inRange(shell, lo, hi) && (minRayleigh * thinnest >= 0x1p-40f);
+        float const eFloor = fmaxf(0.9f * a.planetRadius, a.planetRadius - 27.0f * fminf(a.densityScaleRayleigh, a.densityScaleMie));
+        float const eCeil = a.atmosphereRadius + shell * 0.005f;
+        a.extFloor2 = eFloor * eFloor;
+        a.extCeil2 = eCeil * eCeil;
+    }
     a.rcpH = rcpN(a.lean ? a.H : 1.0f);
     a.rcpDsR = rcpN(a.lean ? a.densityScaleRayleigh : 1.0f);
     a.rcpDsM = rcpN(a.lean ? a.densityScaleMie : 1.0f);
@@ -466,10 +488,18 @@ struct TLut
     float fwidth, fheight;
     // textureCoordFromUnitRange constants (common.glinl:29-32)
     float u_bias, u_scale, v_bias, v_scale;
+    // every texel's rgb lies in [2^-50, 2] (status dword behind the texels, szg_launch.hpp "transmittance LUT block"):
+    // any bilinear tap then lies in [2^-51, 2.01], inside the operand domain of the lean exact division
+    bool moderate;
 };
+SZG_DEV bool tlutTexelModerate(float x, float y, float z)
+{
+    return inRange(x, 0x1p-50f, 2.0f) && inRange(y, 0x1p-50f, 2.0f) && inRange(z, 0x1p-50f, 2.0f);
+}
 SZG_DEV TLut make_tlut(const float4* texels, int w, int h)
 {
     TLut t;
+    t.moderate = reinterpret_cast<const unsigned*>(texels + (size_t)w * (size_t)h)[0] == 0u;
     t.texels = texels;
     t.width = w;
     t.height = h;
@@ -614,6 +644,13 @@ SZG_DEV V3 segmentRatio(const TLut& L, const Atm& a, const RadiusPart& pFrom, fl
     unsigned const signFlip = flip ? 0x80000000u : 0u;
     V3 const Tf = sampleT_at<LEAN>(L, a, pFrom, xorSign(muFrom, signFlip));
     V3 const Tt = sampleT_at<LEAN>(L, a, pTo, xorSign(muTo, signFlip));
+    if (LEAN && L.moderate)
+    {
+        // both taps lie in [2^-51, 2.01]; the quotient is clamped to [0, 1] and then consumed sign-blind
+        V3 const ql = flip ? V3{divN0(Tt.x, Tf.x), divN0(Tt.y, Tf.y), divN0(Tt.z, Tf.z)}
+                           : V3{divN0(Tf.x, Tt.x), divN0(Tf.y, Tt.y), divN0(Tf.z, Tt.z)};
+        return clamp01(ql);
+    }
     V3 const q = flip ? (Tt / Tf) : (Tf / Tt);
     return clamp01(q);
 }
@@ -653,6 +690,7 @@ struct MarchSetup
     float dS, pR, pM, sin_sunRadius, cos_sunRadius;
     float mu_sunAndStep, r_mu, two_r_mu, r2, r_musun;
     bool up;
+    bool extLean; // wave-uniform: the extinction along this wave's rays is of moderate magnitude (Atm::extModerate)
     V3 T_origin;
 };
 
@@ -711,7 +749,16 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         if (!waveAll(t < 0.0000001f))
         {
             V3 const T_end = sampleT_at<LEAN>(L, a, pStep, xorSign(s_mu, m.up ? 0u : 0x80000000u));
-            V3 const ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
+            V3 ratio;
+            if (LEAN && L.moderate)
+            {
+                ratio = clamp01(m.up ? V3{divN0(m.T_origin.x, T_end.x), divN0(m.T_origin.y, T_end.y), divN0(m.T_origin.z, T_end.z)}
+                                     : V3{divN0(T_end.x, m.T_origin.x), divN0(T_end.y, m.T_origin.y), divN0(T_end.z, m.T_origin.z)});
+            }
+            else
+            {
+                ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
+            }
             T_begin = (t < 0.0000001f) ? splat(1.0f) : ratio;
         }
 
@@ -722,7 +769,11 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         V3 const segDir = normalize(end - begin);
         V3 const T_path = segmentRatio<LEAN>(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd,
                                              sqrtX<LEAN>(dot(segDir, segDir)));
-        V3 const integral = (splat(1.0f) - T_path) / ex.extinction;
+        // 1 - T_path is 0 or a multiple of 2^-24; the extinction is in [2^-40, 2^52] when m.extLean
+        V3 const oneMinusT = splat(1.0f) - T_path;
+        V3 const integral = (LEAN && m.extLean) ? V3{divN0(oneMinusT.x, ex.extinction.x), divN0(oneMinusT.y, ex.extinction.y),
+                                                     divN0(oneMinusT.z, ex.extinction.z)}
+                                                : oneMinusT / ex.extinction;
         luminance = luminance + phaseTimesScattering * T_sun * integral * T_begin;
 
         begin = end;
@@ -766,6 +817,7 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     float const rmin2 = (tStar > 0.0f && tStar < sampleDistance) ? m.r2 * (1.0f - mu * mu) : fminf(m.r2, L2);
     bool const lean = a.lean && rmin2 >= a.leanFloor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(sampleDistance, 0.0f, 0x1p30f) &&
                       m.sin_sunRadius >= 0x1p-30f;
+    m.extLean = waveAll(a.extModerate && rmin2 >= a.extFloor2 && fmaxf(m.r2, L2) <= a.extCeil2);
     // wave-uniform choice: one lane outside the domain sends its whole wave down the generic path
     if (waveAll(lean))
     {

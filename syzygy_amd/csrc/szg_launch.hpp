@@ -48,6 +48,12 @@ struct TileArgs
     unsigned block_rows, rank, nranks, local_rows;
 };
 
+// Transmittance LUT block: W*H RGBA32F texels followed by ONE status dword (16 bytes reserved). The dword is 0 when
+// every texel's rgb lies in [2^-50, 2] — the operand domain in which the march may use the lean exact division for
+// transmittance ratios (szg_device.hpp TLut::moderate). launch_transmittance maintains it; launch_lut_range recomputes
+// it for texels written by the caller. Every kernel that takes `tlut` reads the dword behind the texels.
+inline size_t tlut_block_bytes(unsigned W, unsigned H) { return (size_t)W * H * 16u + 16u; }
+hipError_t launch_lut_range(hipStream_t s, float* lut, unsigned W, unsigned H);
 hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, float* lut, unsigned W,
                                 unsigned H);
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,

@@ -412,12 +412,22 @@ def _infinite_coefficient(a):
     a.scatteringMiePerMegameter[0] = float("inf")
 
 
+def _dense_atmosphere(a):  # horizontal optical depths of several hundred: LUT texels underflow, the LUT status word
+    for k in range(3):     # keeps the transmittance quotients on the generic division
+        a.scatteringRayleighPerMegameter[k] *= 40.0
+
+
+def _large_coefficient(a):  # above 2^10: the extinction bound of the lean in-scatter division does not hold
+    a.scatteringMiePerMegameter[:] = [1500.0, 1500.0, 1500.0]
+
+
 def _camera_deep_underground_lean_floor(a):  # shell so thick that Rp - 80 H is the active floor, not 0.9 Rp
     a.altitudeDecayMieMegameters = 0.0004
 
 
 @pytest.mark.parametrize("edit", [_thin_shell, _tiny_density_scale, _absorbing_rayleigh, _scattering_ozone, _absorbing_and_scattering,
                                   _one_nonzero_component, _negative_zero_coefficient, _nan_coefficient, _infinite_coefficient,
+                                  _dense_atmosphere, _large_coefficient,
                                   _camera_deep_underground_lean_floor])
 def test_generic_path_unusual_atmospheres(gpu, edit):
     inp = util.Inputs(128, 72, elevation_degrees=30.0, spots=6, atmosphere_edit=edit)
