@@ -369,7 +369,10 @@ int szg_skyview_record_multiscatter_lut(szg_skyview_t* p, void* stream, uint32_t
                                         const szg_atmosphere_packed* d_atmospheres);
 int szg_skyview_multiscatter_lut(const szg_skyview_t* p, szg_image* out);
 
-/* Accessors to the LUT images the pipeline owns (skyview.hpp:52-97 `map`). */
+/* Accessors to the LUT images the pipeline owns (skyview.hpp:52-97 `map`).
+ * A caller that WRITES the transmittance texels itself (tests upload a LUT) must fetch the image through
+ * szg_skyview_transmittance_lut for each such write: the call marks the LUT as externally written, and the next pass
+ * that consumes it first re-scans the texels (the kernels keep a range flag of the LUT next to it). */
 int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out);
 int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out);
 
