@@ -764,9 +764,20 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
 
         V3 const phaseTimesScattering = ex.scatteringRayleigh * m.pR + ex.scatteringMie * m.pM;
 
-        // sampleTransmittanceLUT_Segment(begin, end), common.glinl:114-136. The segment can be arbitrarily
-        // short (geometry close to the camera), so its normalisation keeps the generic operators.
-        V3 const segDir = normalize(end - begin);
+        // sampleTransmittanceLUT_Segment(begin, end), common.glinl:114-136. The segment can be arbitrarily short
+        // (geometry close to the camera: end - begin may even be 0 and its normal NaN), so normalize() keeps the
+        // generic operators unless the squared length is comfortably normal for the whole wave.
+        V3 const segment = end - begin;
+        float const segment2 = dot(segment, segment);
+        V3 segDir;
+        if (LEAN && waveAll(inRange(segment2, 0x1p-90f, 0x1p60f)))
+        {
+            segDir = segment * divN0(1.0f, sqrtN(segment2)); // = segment * (1 / sqrt(dot)) of normalize()
+        }
+        else
+        {
+            segDir = normalize(segment);
+        }
         V3 const T_path = segmentRatio<LEAN>(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd,
                                              sqrtX<LEAN>(dot(segDir, segDir)));
         // 1 - T_path is 0 or a multiple of 2^-24; the extinction is in [2^-40, 2^52] when m.extLean
