@@ -473,6 +473,34 @@ def test_random_planets_cameras_and_suns(gpu, seed):
     print(f"random frame {seed}: geometry {float((frame.depth > 0).mean()):.2f}, bit-identical fraction {exact:.5f}")
 
 
+def test_uploaded_lut_with_underflowing_texels(gpu):
+    """A transmittance LUT written by the CALLER (here: the oracle's, for an atmosphere so dense that texels underflow to 0)
+    is re-scanned before use (k_lut_range): its quotients must take the generic division — a lean division by a zero
+    texel would give NaN where IEEE gives inf — and the sky-view LUT still equals the oracle's."""
+    inp = util.Inputs(64, 36, elevation_degrees=20.0, atmosphere_edit=_dense_atmosphere)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(128, 32), skyview_extent=(128, 64))
+    tlut = gpu.ob.transmittance_lut(inp.atm, 128, 32, threads=8)
+    assert tlut[..., :3].min() < 2.0 ** -50
+    sky.upload_lut(sky.transmittanceLUT(), tlut)
+    sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    torch.cuda.synchronize()
+    got = sky.download_lut(sky.skyviewLUT())
+    want = gpu.ob.skyview_lut(inp.atm, inp.cam, tlut, 128, 64, threads=8)
+    assert_close(got[..., :3], want[..., :3], atol=1e-12, what="sky-view LUT from an uploaded dense LUT")
+    # then a moderate LUT uploaded into the SAME pipeline: the status is recomputed, results again equal
+    inp2 = util.Inputs(64, 36, elevation_degrees=20.0)
+    cameras2, atmospheres2, _ = staged(gpu, inp2)
+    tlut2 = gpu.ob.transmittance_lut(inp2.atm, 128, 32, threads=8)
+    sky.upload_lut(sky.transmittanceLUT(), tlut2)
+    sky.recordSkyViewLUT(None, 0, atmospheres2, 0, cameras2)
+    torch.cuda.synchronize()
+    got2 = sky.download_lut(sky.skyviewLUT())
+    want2 = gpu.ob.skyview_lut(inp2.atm, inp2.cam, tlut2, 128, 64, threads=8)
+    assert (got2.view(np.uint32) == want2.view(np.uint32))[..., :3].all()
+    sky.destroy()
+
+
 def test_generic_path_camera_far_below_ground(gpu):
     """Unphysical on purpose (the reference has a TODO for it, common.glinl:294): rays whose radius drops under
     0.9 R_planet fail leanRay and use the generic operators; results still equal the oracle's, NaNs included."""
