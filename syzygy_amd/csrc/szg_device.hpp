@@ -76,7 +76,7 @@ SZG_DEV float safeSqrt(float v) { return sqrtf(fmaxf(v, 0.0f)); } // atmosphere/
 // hipcc's correctly rounded `/` and sqrtf() cost ~47 and ~64 cycles per wave64 operation
 // on gfx950 (an fma costs ~2.3): every call carries the denormal/overflow scaling and the
 // special-case fix-up. The sequences below are the SAME algorithms without the scaling
-// (v_rcp_f32 / v_sqrt_f32 seed, Newton, exact fma residual corrections). They return the
+// (v_rcp_f32 / v_rsq_f32 seed, Newton, exact fma residual corrections). They return the
 // IEEE-754 correctly rounded result — bit-identical to `/` and sqrtf() — whenever their
 // operand preconditions hold, and cost ~29 / ~26 cycles; a division whose denominator's
 // refined reciprocal is shared costs ~13. Checked on MI355X: sqrtN == sqrtf for ALL
@@ -130,8 +130,9 @@ SZG_DEV float sqrtN(float x)
 }
 template <bool LEAN> SZG_DEV float sqrtX(float x) { return LEAN ? sqrtN(x) : sqrtf(x); }
 template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
-// (quotients of the divX sites — the two segment cosines and the smoothstep argument — are consumed sign-blind too)
+// exp of a value that is never NaN on a lean path (finite coefficients, radii above the lean floor)
 template <bool LEAN> SZG_DEV float expX(float x) { return LEAN ? szg_expf_notnan(x) : szg_expf(x); }
+// (quotients of the divX sites — the two segment cosines and the smoothstep argument — are consumed sign-blind too)
 template <bool LEAN> SZG_DEV float divX(float a, float b) { return LEAN ? divR0(a, b, rcpN(b)) : a / b; }
 template <bool LEAN> SZG_DEV float divRX(float a, float b, float y) { return LEAN ? divR0(a, b, y) : a / b; }
 SZG_DEV float xorSign(float x, unsigned signMask)
