@@ -271,9 +271,15 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
             march0 = true;
         }
 
-        // camera.comp:379-386: single-bounce reflection. metallic == 0 makes the
-        // whole term an exact zero, so it is skipped.
-        if (m.metallic != 0.0f)
+        // camera.comp:379-386: single-bounce reflection. With metallic == 0 the term is 0 * fresnel * environment: an
+        // exact zero that may be skipped — unless the environment could be NaN or inf (0 * NaN = NaN poisons the pixel in
+        // the reference). It cannot when the extinction is bounded away from 0 along every ray of the shell
+        // (Atm::extModerate), the transmittance LUT is moderate, and both the camera (whose sky-view LUT is sampled)
+        // and the surface (origin of the reflection ray) lie inside the shell; otherwise the term is evaluated.
+        float const cameraR2 = dot(position, position), surfaceR2 = dot(surfacePosition, surfacePosition);
+        bool const environmentFinite = a.extModerate && L.moderate && inRange(cameraR2, a.extFloor2, a.extCeil2) &&
+                                       inRange(surfaceR2, a.extFloor2, a.extCeil2);
+        if (m.metallic != 0.0f || !environmentFinite)
         {
             hasReflection = true;
             V3 const negDir = -direction;

@@ -263,8 +263,12 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
     {
         float const lo = 0x1p-30f, hi = 0x1p30f;
         r.leanOK = (r.isSpot != 0u && inRange(r.falloffDistance, lo, hi) && inRange(r.falloffFactor, lo, hi)) ? 1u : 0u;
+        // A spot light's term for a pixel outside its cone is (colour * strength / falloff) * 0 * brdf: an exact zero only
+        // if every factor is finite. The light's own factors are checked here, the pixel's in k_lights.
+        bool const finite = fabsf(r.colorStrength[0]) <= hi && fabsf(r.colorStrength[1]) <= hi && fabsf(r.colorStrength[2]) <= hi;
+        r.pad[0] = (r.leanOK != 0u && finite) ? 1u : 0u; // "cullable"
     }
-    r.pad[0] = r.pad[1] = 0u;
+    r.pad[1] = 0u;
     out[i] = r;
 }
 
@@ -290,7 +294,7 @@ SZG_DEV float divU(bool lean, float a, float b, float y) { return lean ? divR(a,
 SZG_DEV float sqrtU(bool lean, float x) { return lean ? sqrtN(x) : sqrtf(x); }
 
 // One light's term of the sum (lights.comp:141-161), exact.
-SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool positionModerate, V3 viewDirection)
+SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool positionModerate, V3 viewDirection, bool cullable)
 {
     const float* R = L.shadowRows;
     // shadowMatrix * vec4(position, 1), rows summed left to right
@@ -322,7 +326,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
         // cull needs no square root. x / 0.5 == x * 2 exactly.
         float const ddx = sx - 0.5f, ddy = sy - 0.5f;
         float const q = ddx * ddx + ddy * ddy;
-        if (q >= 0.25f)
+        if (q >= 0.25f && cullable)
         {
             return splat(0.0f);
         }
@@ -424,17 +428,30 @@ __global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug
 
         float const hi = 0x1p30f;
         bool const positionModerate = fabsf(m.position.x) <= hi && fabsf(m.position.y) <= hi && fabsf(m.position.z) <= hi;
-        // Light records are wave-uniform: they are fetched with scalar loads and live in SGPRs.
+        // every per-pixel factor of a light's term is finite (see k_light_prep): only then is 0 * term an exact zero and a
+        // pixel outside a spot light's cone may skip that light (a NaN anywhere poisons the sum in the reference)
+        float const big = 0x1p120f;
+        bool const pixelFinite = positionModerate && fabsf(viewDirection.x) <= 2.0f && fabsf(viewDirection.y) <= 2.0f &&
+                                 fabsf(viewDirection.z) <= 2.0f && fabsf(m.normal.x) <= big && fabsf(m.normal.y) <= big &&
+                                 fabsf(m.normal.z) <= big && fabsf(m.diffuse.x) <= big && fabsf(m.diffuse.y) <= big &&
+                                 fabsf(m.diffuse.z) <= big && fabsf(m.reflectance.x) <= big && fabsf(m.reflectance.y) <= big &&
+                                 fabsf(m.reflectance.z) <= big && fabsf(m.occlusion) <= big && fabsf(m.normalization) <= big &&
+                                 fabsf(m.specularPower) <= big;
+        // Light records are wave-uniform: they are fetched with scalar loads and live in SGPRs. Culling is decided per
+        // wave: when some pixel of the wave has a non-finite factor the whole wave evaluates every light (no term of its
+        // sum may be dropped); the flag of the light itself is wave-uniform anyway.
+        bool const waveFinite = waveAll(pixelFinite);
 #pragma unroll 1
         for (unsigned i = 0; i < lightCount; i++)
         {
             const LightRec* __restrict__ L = lights + i;
             LightCull const cur = loadCull(L); // (prefetching light i+1's rows here measured 20 % slower)
-            if (cur.isSpot != 0u && surelyOutsideCone(cur, m.position))
+            bool const cullable = waveFinite && L->pad[0] != 0u;
+            if (cur.isSpot != 0u && cullable && surelyOutsideCone(cur, m.position))
             {
                 continue;
             }
-            sum = sum + lightContribution(*L, m, positionModerate, viewDirection);
+            sum = sum + lightContribution(*L, m, positionModerate, viewDirection, cullable);
         }
     }
     row_ptr<uint2>(color, y)[x] = pack_unorm16x4(sum.x, sum.y, sum.z, 1.0f);

@@ -24,7 +24,7 @@ struct LightRec
     unsigned mapWidth, mapHeight;
     unsigned mapPitchFloats;
     unsigned leanOK; // falloffDistance / falloffFactor / colour*strength of moderate magnitude (lean exact ops allowed)
-    unsigned pad[2];
+    unsigned pad[2]; // pad[0]: the light's own factors are finite and non-zero where they divide (a culled pixel's term is an exact 0)
 };
 static_assert(sizeof(LightRec) == 144, "LightRec layout");
 

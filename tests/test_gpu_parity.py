@@ -152,12 +152,14 @@ def test_gbuffer_fill_bit_exact(gpu, size):
 # ---------------------------------------------------------------------------
 # lights pass
 # ---------------------------------------------------------------------------
-def run_lights_case(gpu, W, H, spots, skip, elevation=70.0, shadow=None, tile=None):
+def run_lights_case(gpu, W, H, spots, skip, elevation=70.0, shadow=None, tile=None, poison=None):
     inp = util.Inputs(W, H, elevation_degrees=elevation, spots=spots)
     cameras, atmospheres, lights = staged(gpu, inp)
     rows = H if tile is None else tile.local_rows
     frame = gpu.ob.HostFrame(W, rows)
     gpu.ob.gbuffer_fill(frame, inp.rect, tile, inp.cam, inp.synthetic.fill, threads=8)
+    if poison is not None:
+        poison(frame)
     shadow_host = None
     keep = []
     deferred = gpu.pl.DeferredShadingPipeline((W, rows), max_spot_lights=max(spots, 1), max_shadow_maps=spots + 2)
@@ -189,6 +191,26 @@ def test_lights_match_oracle(gpu, spots, skip):
     assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
     assert (got_q[..., 3] == 65535).all()
     print(f"lights spots={spots} skip={skip}: worst/tol {worst:.3f}")
+
+
+def test_lights_nan_gbuffer_poisons_culled_lights_too(gpu):
+    """A pixel outside every spot cone still multiplies each light's term by its BRDF in the reference (lights.comp:141-161):
+    0 * NaN = NaN. With non-finite G-buffer values (here NaN / inf normals, specular and ORM in patches of geometry) the kernel
+    may not skip culled lights for the affected waves; the NaN pattern must equal the oracle's — with the moon skipped too
+    (skip = 2), so that no always-evaluated light hides the difference."""
+    def poison(frame):
+        geometry = np.argwhere(frame.depth > 0)
+        rng = np.random.default_rng(7)
+        for plane, value in ((frame.normal, np.nan), (frame.specular, np.inf), (frame.orm, np.nan), (frame.normal, -np.inf)):
+            for (y, x) in geometry[rng.choice(len(geometry), 40, replace=False)]:
+                plane[y, x, :3] = value
+
+    got, got_q, frame = run_lights_case(gpu, 160, 90, 24, 2, poison=poison)
+    assert np.isnan(frame.debug).any() and not np.isnan(frame.debug).all()
+    assert (np.isnan(got) == np.isnan(frame.debug)).all()
+    ok = ~np.isnan(got)
+    assert (got.view(np.uint32)[ok] == frame.debug.view(np.uint32)[ok]).all()
+    assert (got_q == frame.color).all()
 
 
 def test_lights_ragged_extent(gpu):
@@ -471,6 +493,49 @@ def test_random_planets_cameras_and_suns(gpu, seed):
     assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
     exact = float((got.view(np.uint32) == frame.debug.view(np.uint32)).mean())
     print(f"random frame {seed}: geometry {float((frame.depth > 0).mean()):.2f}, bit-identical fraction {exact:.5f}")
+
+
+@pytest.mark.parametrize("seed", [237, 345, 101, 333, 512])
+def test_random_frames_including_nan_environments(gpu, seed):
+    """A wider random family (sun down to -15 degrees, density scales so small that the extinction underflows to exactly
+    0 in the upper shell, coefficient vectors replaced or scaled by 10^+-1.5, cameras from 1 m to 150 km). Seeds 237 and
+    345 make the reference math produce NaN in half of the sky-view LUT; 0 * NaN then poisons even non-metal pixels through
+    the reflection term (camera.comp:379-386), which the kernel may therefore skip only when the environment is provably
+    finite. Bit-identical including the NaN pattern."""
+    from syzygy_amd import scene
+
+    rng = np.random.default_rng(seed)
+
+    def edit(a):
+        if rng.random() < 0.7:
+            a.planetRadiusMegameters = float(rng.uniform(1.0, 12.0))
+            a.atmosphereRadiusMegameters = a.planetRadiusMegameters + float(rng.uniform(0.02, 0.4))
+        a.altitudeDecayRayleighMegameters = float(rng.uniform(0.002, 0.03))
+        a.altitudeDecayMieMegameters = float(rng.uniform(0.0005, 0.005))
+        for field in ("scatteringRayleighPerMegameter", "absorptionRayleighPerMegameter", "scatteringMiePerMegameter",
+                      "scatteringOzonePerMegameter", "absorptionOzonePerMegameter"):
+            vals = getattr(a, field)
+            scale = float(10.0 ** rng.uniform(-1.5, 1.5))
+            for k in range(3):
+                vals[k] = vals[k] * scale
+            if rng.random() < 0.25:
+                for k in range(3):
+                    vals[k] = float(rng.uniform(0, 3))
+        a.sunAngularRadius = float(rng.uniform(0.002, 0.05))
+
+    cam = scene.default_camera()
+    cam.cameraPosition[:] = [float(rng.uniform(-30, 30)), float(-10.0 ** rng.uniform(0.0, 5.2)), float(rng.uniform(-40, 10))]
+    cam.eulerAngles[:] = [float(rng.uniform(-1.2, 1.2)), float(rng.uniform(-3.1, 3.1)), 0.0]
+    cam.fovDegrees = float(rng.uniform(30.0, 100.0))
+    elevation = float(rng.uniform(-15.0, 90.0))
+    inp = util.Inputs(128, 72, elevation_degrees=elevation, spots=int(rng.integers(0, 6)), camera=cam, atmosphere_edit=edit)
+    got, got_q = render_gpu(gpu, inp, lut=((128, 32), (128, 64)))
+    frame = render_oracle(gpu, inp, lut=((128, 32), (128, 64)))
+    assert (np.isnan(got) == np.isnan(frame.debug)).all(), "NaN patterns differ"
+    same = (got.view(np.uint32) == frame.debug.view(np.uint32)) | np.isnan(got)
+    assert same.all(), f"{(~same).sum()} values differ"
+    assert (got_q == frame.color).all()
+    print(f"random frame {seed}: elevation {elevation:.1f}, NaN fraction {float(np.isnan(got).mean()):.2f}")
 
 
 def test_uploaded_lut_with_underflowing_texels(gpu):
