@@ -1,7 +1,12 @@
-// Checks szg_device.hpp's lean division against hipcc's correctly rounded `/` on gfx950. The operand space (2^64 pairs)
-// cannot be enumerated, so besides 4.3e9 uniformly random mantissa pairs per exponent window the check walks the families
-// where Newton-Raphson division is known to be fragile: quotients next to 1 (a = b +- k ulp), denominators with an
-// all-ones or all-zero mantissa tail, numerators that are exact multiples of the denominator, and zero numerators.
+// Checks szg_device.hpp's lean division (v_rcp + one Newton step = reciprocal; one residual correction = quotient)
+// against hipcc's correctly rounded `/` on gfx950.
+//   1. Premise of Markstein's theorem, exhaustively: rcpN(b) == RN(1 / b) for every b with |b| in [2^-60, 2^60].
+//   2. The theorem's exception class, exhaustively: the 120 denominators 1.11..1 * 2^e of the domain against every numerator
+//      significand (x 5 exponents x 2 signs).
+//   3. 4096 random denominators against every numerator significand.
+//   4. The operand space (2^64 pairs) cannot be enumerated: 4.3e9 random mantissa pairs per exponent window and family —
+//      quotients next to 1 (a = b +- k ulp), denominators with an all-ones or all-zeros mantissa tail, numerators that are
+//      exact multiples of the denominator, zero numerators.
 // divN must match bit for bit; divN0 (no sign fix) must match except for the sign of a zero quotient.
 // Build: hipcc -O3 --offload-arch=gfx950 -std=c++17 -ffp-contract=off -Iinclude -Isyzygy_amd/csrc tools/verify_div.hip -o verify_div
 #include <hip/hip_runtime.h>
@@ -71,10 +76,87 @@ __global__ void check(unsigned long long* out, int emin, int emax, int family)
     atomicAdd(out + 2, 4096ull);
 }
 
+// 1. rcpN(b) == RN(1 / b)
+__global__ void checkReciprocal(unsigned long long* out)
+{
+    unsigned long long cnt = 0, tot = 0;
+    for (unsigned long long k = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; k < (1ull << 32);
+         k += (unsigned long long)gridDim.x * blockDim.x)
+    {
+        float const b = __uint_as_float((unsigned)k), ab = fabsf(b);
+        if (!(ab >= 0x1p-60f && ab <= 0x1p60f))
+        {
+            continue;
+        }
+        tot++;
+        cnt += __float_as_uint(szg::rcpN(b)) != __float_as_uint(1.0f / b);
+    }
+    atomicAdd(out + 0, cnt);
+    atomicAdd(out + 2, tot);
+}
+// 2. / 3. one denominator against every numerator significand
+__global__ void checkDenominator(unsigned long long* out, unsigned denominatorBits)
+{
+    unsigned long long bad = 0, bad0 = 0, tot = 0;
+    float const b = __uint_as_float(denominatorBits);
+    int const eb = (int)((denominatorBits >> 23) & 0xFFu);
+    for (unsigned long long k = blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; k < (1ull << 24);
+         k += (unsigned long long)gridDim.x * blockDim.x)
+    {
+        for (int de = -2; de <= 2; de++)
+        {
+            float a = __uint_as_float(((unsigned)(eb + de) << 23) | ((unsigned)k & 0x7FFFFFu));
+            a = (k >> 23) ? -a : a;
+            compare(a, b, bad, bad0);
+            tot++;
+        }
+    }
+    atomicAdd(out + 0, bad);
+    atomicAdd(out + 1, bad0);
+    atomicAdd(out + 2, tot);
+}
+
 int main()
 {
     unsigned long long* d;
     (void)hipMalloc(&d, 24);
+    {
+        unsigned long long h[3];
+        (void)hipMemset(d, 0, 24);
+        checkReciprocal<<<4096, 256>>>(d);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        std::printf("rcpN(b) != RN(1/b): %llu of %llu values of b with |b| in [2^-60, 2^60] (exhaustive)\n", h[0], h[2]);
+        int failedHere = h[0] != 0ull;
+        (void)hipMemset(d, 0, 24);
+        for (int e = -60; e <= 59; e++)
+        {
+            checkDenominator<<<512, 256>>>(d, ((unsigned)(e + 127) << 23) | 0x7FFFFFu);
+        }
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        std::printf("all-ones denominators 1.11..1 * 2^e, e = -60..59, every numerator significand: %llu pairs, divN mismatches %llu, divN0 %llu\n",
+                    h[2], h[0], h[1]);
+        failedHere += (h[0] != 0ull) + (h[1] != 0ull);
+        (void)hipMemset(d, 0, 24);
+        unsigned s = 12345u;
+        for (int i = 0; i < 4096; i++)
+        {
+            s = s * 1664525u + 1013904223u;
+            unsigned const mant = (s >> 9) & 0x7FFFFFu;
+            s = s * 1664525u + 1013904223u;
+            unsigned const e = 127u - 60u + (s >> 8) % 120u;
+            checkDenominator<<<512, 256>>>(d, (e << 23) | mant | ((s & 1u) << 31));
+        }
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h, d, 24, hipMemcpyDeviceToHost);
+        std::printf("4096 random denominators, every numerator significand: %llu pairs, divN mismatches %llu, divN0 %llu\n", h[2], h[0], h[1]);
+        failedHere += (h[0] != 0ull) + (h[1] != 0ull);
+        if (failedHere != 0)
+        {
+            return 1;
+        }
+    }
     const char* names[5] = {"random mantissas", "quotients next to 1", "denominator tails 1..1 / 0..0", "exact multiples", "zero numerators"};
     int failed = 0;
     for (auto range : {std::pair<int, int>{-60, 60}, std::pair<int, int>{-30, 30}, std::pair<int, int>{-1, 1}})
