@@ -129,7 +129,18 @@ SZG_DEV float sqrtN(float x)
     float const r = __builtin_fmaf(-s, s, x);
     return __builtin_fmaf(r, h, s);
 }
+// sqrtN for x in [2^-96, FLT_MAX] (not 0): without the max()
+SZG_DEV float sqrtP(float x)
+{
+    float const y = __builtin_amdgcn_rsqf(x);
+    float const s = x * y;
+    float const h = 0.5f * y;
+    float const r = __builtin_fmaf(-s, s, x);
+    return __builtin_fmaf(r, h, s);
+}
 template <bool LEAN> SZG_DEV float sqrtX(float x) { return LEAN ? sqrtN(x) : sqrtf(x); }
+// square root of a squared radius / squared length that a lean path knows to be positive (>= the squared lean floor)
+template <bool LEAN> SZG_DEV float sqrtPX(float x) { return LEAN ? sqrtP(x) : sqrtf(x); }
 template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
 // exp of a value that is never NaN on a lean path (finite coefficients, radii above the lean floor)
 template <bool LEAN> SZG_DEV float expX(float x) { return LEAN ? szg_expf_notnan(x) : szg_expf(x); }
@@ -702,7 +713,7 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
     // `end` of step i and `begin` of step i+1 are the same expression (common.glinl:386-387),
     // so its length and radius part are carried from one iteration to the next.
     V3 begin = m.origin - (0.0f * m.dS) * m.scatteringDir;
-    float lenBegin = sqrtX<LEAN>(dot(begin, begin));
+    float lenBegin = sqrtPX<LEAN>(dot(begin, begin));
     RadiusPart pBegin = radiusPart<LEAN>(L, a, lenBegin);
 #pragma unroll 1
     for (unsigned i = 0; i < 32u; i++)
@@ -710,11 +721,12 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         float const fi = (float)i;
         float const t = fi * m.dS;
         V3 const end = m.origin - ((float)(i + 1u) * m.dS) * m.scatteringDir;
-        float const lenEnd = sqrtX<LEAN>(dot(end, end));
+        float const lenEnd = sqrtPX<LEAN>(dot(end, end));
         RadiusPart const pEnd = radiusPart<LEAN>(L, a, lenEnd);
 
         // stepRadiusMu(originStep, t), common.glinl:329-331
-        float const s_radius = safeSqrtX<LEAN>(t * t + m.two_r_mu * t + m.r2);
+        // (on a lean path this is a squared radius above the lean floor: neither the clamp to 0 nor sqrtN's guard is needed)
+        float const s_radius = LEAN ? sqrtP(t * t + m.two_r_mu * t + m.r2) : safeSqrt(t * t + m.two_r_mu * t + m.r2);
         float const yS = LEAN ? rcpN(s_radius) : 0.0f;
         float const s_mu = divRX<LEAN>(m.r_mu + t, s_radius, yS);
         float const s_musun = divRX<LEAN>(m.r_musun + t * m.mu_sunAndStep, s_radius, yS);
@@ -774,14 +786,14 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         V3 segDir;
         if (LEAN && waveAll(inRange(segment2, 0x1p-90f, 0x1p60f)))
         {
-            segDir = segment * divN0(1.0f, sqrtN(segment2)); // = segment * (1 / sqrt(dot)) of normalize()
+            segDir = segment * divN0(1.0f, sqrtP(segment2)); // = segment * (1 / sqrt(dot)) of normalize()
         }
         else
         {
             segDir = normalize(segment);
         }
         V3 const T_path = segmentRatio<LEAN>(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd,
-                                             sqrtX<LEAN>(dot(segDir, segDir)));
+                                             sqrtPX<LEAN>(dot(segDir, segDir)));
         // 1 - T_path is 0 or a multiple of 2^-24; the extinction is in [2^-40, 2^52] when m.extLean
         V3 const oneMinusT = splat(1.0f) - T_path;
         V3 const integral = (LEAN && m.extLean) ? V3{divN0(oneMinusT.x, ex.extinction.x), divN0(oneMinusT.y, ex.extinction.y),

@@ -14,7 +14,7 @@ __global__ void k(unsigned long long* bad, unsigned* firstBad, unsigned lo, unsi
          b += (unsigned long long)gridDim.x * blockDim.x)
     {
         float const x = __uint_as_float((unsigned)b);
-        if (__float_as_uint(sqrtf(x)) != __float_as_uint(szg::sqrtN(x)))
+        if (__float_as_uint(sqrtf(x)) != __float_as_uint(szg::sqrtN(x)) || (x != 0.0f && __float_as_uint(sqrtf(x)) != __float_as_uint(szg::sqrtP(x))))
         {
             cnt++;
             atomicMin(firstBad, (unsigned)b);
@@ -41,6 +41,6 @@ int main()
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(&z, bad, 8, hipMemcpyDeviceToHost);
     (void)hipMemcpy(&f, fb, 4, hipMemcpyDeviceToHost);
-    std::printf("sqrtN vs sqrtf over [2^-96, FLT_MAX] and 0: %llu mismatches (first %08x)\n", z, f);
+    std::printf("sqrtN (and sqrtP, without 0) vs sqrtf over [2^-96, FLT_MAX] and 0: %llu mismatches (first %08x)\n", z, f);
     return z == 0 ? 0 : 1;
 }
