@@ -38,6 +38,7 @@ def lib():
         abi.bind(handle, abi.ABI_FUNCTIONS)
         abi.bind(handle, abi.HOST_FUNCTIONS)
         abi.bind(handle, abi.RASTER_FUNCTIONS)
+        abi.bind(handle, abi.ASSET_FUNCTIONS)
         if handle.szg_abi_version() != abi.SZG_ABI_VERSION:
             raise RuntimeError("libszg_hip.so ABI version mismatch")
         _LIB = handle

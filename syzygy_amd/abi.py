@@ -403,6 +403,54 @@ RASTER_FUNCTIONS = {
     ),
 }
 
+# include/szg/assets.h
+SZG_ERR_IO = -6
+SZG_ERR_PARSE = -7
+SZG_GLTF_DECODE_BUFFER_VIEW_IMAGES = 1
+SZG_MAP_COLOR, SZG_MAP_NORMAL, SZG_MAP_ORM = 0, 1, 2
+SZG_DEFAULT_MAP_DIMENSIONS = 64
+
+
+class AssetTexture(C.Structure):
+    _fields_ = [("rgba", P(C.c_uint8)), ("width", U32), ("height", U32), ("srgb", U32), ("name", C.c_char_p)]
+
+
+class AssetMaterial(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("color", AssetTexture), ("normal", AssetTexture), ("orm", AssetTexture)]
+
+
+class AssetSurface(C.Structure):
+    _fields_ = [("first_index", U32), ("index_count", U32), ("material", C.c_int32)]
+
+
+class AssetMesh(C.Structure):
+    _fields_ = [
+        ("name", C.c_char_p),
+        ("vertices", VP),
+        ("vertex_count", U32),
+        ("indices", P(U32)),
+        ("index_count", U32),
+        ("surfaces", P(AssetSurface)),
+        ("surface_count", U32),
+        ("vertex_bounds", AABB),
+        ("gltf_mesh_index", C.c_int32),
+    ]
+
+
+ASSET_FUNCTIONS = {
+    "szg_gltf_load_file": (C.c_int, [C.c_char_p, U32, P(VP)]),
+    "szg_gltf_load_memory": (C.c_int, [VP, C.c_size_t, C.c_int, C.c_char_p, U32, P(VP)]),
+    "szg_gltf_destroy": (None, [VP]),
+    "szg_gltf_mesh_count": (U32, [VP]),
+    "szg_gltf_mesh": (C.c_int, [VP, U32, P(AssetMesh)]),
+    "szg_gltf_material_count": (U32, [VP]),
+    "szg_gltf_material": (C.c_int, [VP, U32, P(AssetMaterial)]),
+    "szg_gltf_warnings": (C.c_char_p, [VP]),
+    "szg_default_material_map": (C.c_int, [C.c_int, P(C.c_uint8)]),
+    "szg_decode_image_rgba": (C.c_int, [VP, C.c_size_t, P(U32), P(U32), P(P(C.c_uint8))]),
+    "szg_free_rgba": (None, [P(C.c_uint8)]),
+}
+
 HOST_FUNCTIONS = {
     "szg_forward_from_eulers": (None, [P(C.c_float), P(C.c_float)]),
     "szg_eulers_from_forward": (None, [P(C.c_float), P(C.c_float)]),

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "szg/abi.h"
+#include "szg_internal.hpp"
 #include "szg_launch.hpp"
 
 namespace
@@ -293,6 +294,12 @@ struct szg_deferred
     size_t rasterDrawCapacity = 0;
     szg::RasterBuffers raster;
 };
+
+void szg::set_last_error(const char* message)
+{
+    snprintf(g_error, sizeof g_error, "%s", message != nullptr ? message : "");
+    fprintf(stderr, "[szg] error: %s\n", g_error);
+}
 
 extern "C" {
 

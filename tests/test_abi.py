@@ -1,5 +1,5 @@
 """The C-ABI library loads on a machine without a GPU, exports every symbol that
-include/szg/abi.h, include/szg/host.h and include/szg/raster.h declare, keeps the reference's struct sizes,
+include/szg/abi.h, include/szg/host.h, include/szg/raster.h and include/szg/assets.h declare, keeps the reference's struct sizes,
 and fails loudly (no CPU fallback) when asked to create a pipeline without a device."""
 import ctypes as C
 import os
@@ -24,7 +24,7 @@ def test_library_is_in_tree():
 
 
 @pytest.mark.parametrize("header,table", [("abi.h", abi.ABI_FUNCTIONS), ("host.h", abi.HOST_FUNCTIONS),
-                                          ("raster.h", abi.RASTER_FUNCTIONS)])
+                                          ("raster.h", abi.RASTER_FUNCTIONS), ("assets.h", abi.ASSET_FUNCTIONS)])
 def test_every_declared_symbol_is_exported_and_bound(header, table):
     handle = C.CDLL(library_path())
     names = declared_symbols(header)

@@ -1,0 +1,428 @@
+"""include/szg/assets.h: glTF 2.0 / GLB / PNG -> the arrays the raster passes consume (assets/assets.cpp:406-1092).
+
+The reference's parsers (fastgltf, stb_image) are third-party code that is not in /root/reference and its only asset
+(assets/sphere.glb) is a git-LFS pointer, so there are no reference fixtures: PARITY UNPINNED. The files below are written
+by tests/gltf_writer.py, an encoder that shares no code with the loader, and every array is compared exactly."""
+import json
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+from syzygy_amd import abi, assets, meshes
+from tests import gltf_writer as gw
+
+
+def _expand_to_rgba8(samples, color_type, depth, palette=None, trns=None):
+    """What stb_image returns for a 4-channel request, restated with numpy."""
+    s = np.asarray(samples).astype(np.uint32)
+    if s.ndim == 2:
+        s = s[..., None]
+    h, w, _ = s.shape
+    out = np.zeros((h, w, 4), np.uint8)
+    if color_type == 3:
+        pal = np.zeros((256, 4), np.uint8)
+        pal[:, 3] = 255
+        p = np.asarray(palette, np.uint8).reshape(-1, 3)
+        pal[: len(p), :3] = p
+        if trns is not None:
+            pal[: len(trns), 3] = np.frombuffer(bytes(trns), np.uint8)
+        return pal[s[..., 0]]
+    scale = {1: 255, 2: 85, 4: 17, 8: 1}.get(depth)
+    v = (s >> 8) if depth == 16 else s * scale
+    alpha = np.full((h, w), 255, np.uint32)
+    if trns is not None:
+        key = np.frombuffer(bytes(trns), ">u2").astype(np.uint32)
+        match = (s == key).all(-1) if depth == 16 else (v == (key & 255) * scale).all(-1)
+        alpha = np.where(match, 0, 255)
+    if color_type == 0:
+        out[..., 0] = out[..., 1] = out[..., 2] = v[..., 0]
+        out[..., 3] = alpha
+    elif color_type == 2:
+        out[..., :3] = v
+        out[..., 3] = alpha
+    elif color_type == 4:
+        out[..., 0] = out[..., 1] = out[..., 2] = v[..., 0]
+        out[..., 3] = v[..., 1]
+    else:
+        out[...] = v
+    return out
+
+
+PNG_CASES = [(ct, d) for ct, ds in {0: (1, 2, 4, 8, 16), 2: (8, 16), 3: (1, 2, 4, 8), 4: (8, 16), 6: (8, 16)}.items() for d in ds]
+
+
+@pytest.mark.parametrize("color_type,depth", PNG_CASES)
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_every_colour_type_and_depth(color_type, depth, interlace):
+    rng = np.random.default_rng(color_type * 100 + depth)
+    for w, h in [(1, 1), (3, 5), (9, 7), (33, 17)]:
+        ch = gw.CHANNELS[color_type]
+        samples = rng.integers(0, 1 << depth, (h, w, ch), dtype=np.uint32)
+        palette = rng.integers(0, 256, (min(1 << depth, 256), 3), dtype=np.uint8) if color_type == 3 else None
+        png = gw.png_encode(samples, color_type, depth, palette=palette, interlace=interlace, seed=w * h)
+        got = assets.decode_image_rgba(png)
+        assert got.shape == (h, w, 4)
+        assert (got == _expand_to_rgba8(samples, color_type, depth, palette)).all()
+
+
+def test_png_transparency_chunks():
+    rng = np.random.default_rng(5)
+    # palette alpha for the first entries only
+    samples = rng.integers(0, 16, (11, 13, 1), dtype=np.uint32)
+    palette = rng.integers(0, 256, (16, 3), dtype=np.uint8)
+    trns = bytes([0, 10, 200, 255, 7])
+    got = assets.decode_image_rgba(gw.png_encode(samples, 3, 4, palette=palette, trns=trns))
+    assert (got == _expand_to_rgba8(samples, 3, 4, palette, trns)).all()
+    # colour keys: grey at 2, 8 and 16 bits, RGB at 8 and 16 bits; the key value is made to occur
+    for color_type, depth in [(0, 2), (0, 8), (0, 16), (2, 8), (2, 16)]:
+        ch = gw.CHANNELS[color_type]
+        samples = rng.integers(0, 1 << depth, (9, 10, ch), dtype=np.uint32)
+        key = samples[4, 4].copy()
+        samples[1, 2] = key
+        samples[7, 0] = key
+        trns = np.asarray(key, ">u2").tobytes()
+        got = assets.decode_image_rgba(gw.png_encode(samples, color_type, depth, trns=trns))
+        want = _expand_to_rgba8(samples, color_type, depth, None, trns)
+        assert (want[..., 3] == 0).sum() >= 3
+        assert (got == want).all()
+
+
+@pytest.mark.parametrize("level,strategy", [(0, zlib.Z_DEFAULT_STRATEGY), (6, zlib.Z_FIXED), (9, zlib.Z_DEFAULT_STRATEGY),
+                                            (1, zlib.Z_HUFFMAN_ONLY), (6, zlib.Z_RLE)])
+def test_png_every_deflate_block_type_and_split_idat(level, strategy):
+    rng = np.random.default_rng(level)
+    # smooth + noisy content so that dynamic blocks carry long matches and literals alike
+    y, x = np.mgrid[0:150, 0:211]
+    rgba = np.stack([(x * 3) & 255, (y * 5) & 255, (x + y) & 255, np.full_like(x, 255)], -1).astype(np.uint8)
+    rgba[40:90, 50:160] = rng.integers(0, 256, (50, 110, 4), dtype=np.uint8)
+    png = gw.png_rgba8(rgba, level=level, strategy=strategy, idat_split=997,
+                       extra_chunks=[(b"gAMA", (45455).to_bytes(4, "big")), (b"tEXt", b"Comment\0ignored")])
+    assert (assets.decode_image_rgba(png) == rgba).all()
+
+
+def test_png_rejects_what_it_cannot_decode():
+    rgba = np.full((4, 4, 4), 77, np.uint8)
+    png = gw.png_rgba8(rgba)
+    for bad in [b"", b"\xff\xd8\xff\xe0" + b"\0" * 64, png[:20], png[:-16], png[:8] + png[8 + 25:],
+                png.replace(b"IHDR", b"IHDX"), gw.png_rgba8(rgba, extra_chunks=[(b"CrIT", b"x")])]:
+        with pytest.raises(assets.AssetError):
+            assets.decode_image_rgba(bad)
+    # a corrupted deflate stream or a bad header never crashes; it either fails or (harmless bit) still decodes
+    rng = np.random.default_rng(0)
+    big = gw.png_rgba8(rng.integers(0, 256, (40, 40, 4), dtype=np.uint8))
+    for k in range(400):
+        mutated = bytearray(big)
+        for _ in range(1 + k % 3):
+            mutated[int(rng.integers(8, len(mutated)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            assets.decode_image_rgba(bytes(mutated))
+        except assets.AssetError:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# meshes
+# ---------------------------------------------------------------------------------------------------------------
+def _flip(v):
+    out = np.array(v, np.float32, copy=True)
+    out[:, 1] *= np.float32(-1.0)
+    return out
+
+
+def _two_primitive_asset():
+    rng = np.random.default_rng(42)
+    b = gw.GltfBuilder()
+    # primitive 0: float attributes, interleave padding, u16 indices, normalized u16 uvs, u8 VEC4 colours
+    n0 = 37
+    p0 = rng.normal(0, 3, (n0, 3)).astype(np.float32)
+    nr0 = rng.normal(0, 1, (n0, 3)).astype(np.float32)
+    uv0 = rng.integers(0, 65536, (n0, 2)).astype(np.uint16)
+    c0 = rng.integers(0, 256, (n0, 4)).astype(np.uint8)
+    i0 = rng.integers(0, n0, 60).astype(np.uint16)
+    # primitive 1: sparse positions over a base, no normals / uvs, float VEC3 colours, u8 indices, signed normalized normals absent
+    n1 = 20
+    base = rng.normal(0, 1, (n1, 3)).astype(np.float32)
+    sparse_at = np.array([1, 7, 19])
+    sparse_values = rng.normal(10, 1, (3, 3)).astype(np.float32)
+    p1 = base.copy()
+    p1[sparse_at] = sparse_values
+    c1 = rng.random((n1, 3)).astype(np.float32)
+    i1 = rng.integers(0, n1, 30).astype(np.uint8)
+    # primitive 2: u32 indices, int8 normalized normals, int16 normalized uvs (both legal per the glTF quantisation rules)
+    n2 = 9
+    p2 = rng.normal(0, 2, (n2, 3)).astype(np.float32)
+    nr2 = rng.integers(-128, 128, (n2, 3)).astype(np.int8)
+    uv2 = rng.integers(-32768, 32768, (n2, 2)).astype(np.int16)
+    i2 = rng.integers(0, n2, 12).astype(np.uint32)
+    prims = [
+        {"attributes": {"POSITION": b.accessor(p0, stride_pad=4, offset_pad=8), "NORMAL": b.accessor(nr0, stride_pad=12),
+                        "TEXCOORD_0": b.accessor(uv0, normalized=True), "COLOR_0": b.accessor(c0, normalized=True)},
+         "indices": b.accessor(i0), "material": 1},
+        {"attributes": {"POSITION": b.sparse_accessor(base, sparse_at, sparse_values), "COLOR_0": b.accessor(c1)},
+         "indices": b.accessor(i1), "mode": 4},
+        {"attributes": {"POSITION": b.accessor(p2), "NORMAL": b.accessor(nr2, normalized=True),
+                        "TEXCOORD_0": b.accessor(uv2, normalized=True)},
+         "indices": b.accessor(i2), "material": 0, "mode": 5},
+    ]
+    b.doc["meshes"] = [{"name": "thing", "primitives": prims}]
+    b.doc["materials"] = [{"name": "m0"}, {"name": "m1"}]
+    want = {"p": [p0, p1, p2], "i": [i0, i1, i2], "nr0": nr0, "uv0": uv0, "c0": c0, "c1": c1, "nr2": nr2, "uv2": uv2}
+    return b, want
+
+
+def _check_two_primitive_asset(a, want):
+    assert len(a.meshes) == 1
+    m = a.meshes[0]
+    assert m.name == "mesh_thing" and m.gltf_mesh_index == 0
+    p0, p1, p2 = want["p"]
+    i0, i1, i2 = want["i"]
+    n0, n1, n2 = len(p0), len(p1), len(p2)
+    assert len(m.vertices) == n0 + n1 + n2
+    # positions: FLIP_Y (assets.cpp:1046-1054)
+    assert (m.vertices["position"] == _flip(np.concatenate([p0, p1, p2]))).all()
+    # indices rebased onto the mesh's vertex array (assets.cpp:980-985), surfaces in primitive order
+    assert (m.indices == np.concatenate([i0.astype(np.uint32), i1.astype(np.uint32) + n0, i2.astype(np.uint32) + n0 + n1])).all()
+    assert m.surfaces == [(0, 60, 1), (60, 30, -1), (90, 12, 0)]
+    v0, v1, v2 = m.vertices[:n0], m.vertices[n0 : n0 + n1], m.vertices[n0 + n1 :]
+    assert (v0["normal"] == _flip(want["nr0"])).all()
+    assert (v0["uv_x"] == (want["uv0"][:, 0].astype(np.float64) / 65535.0).astype(np.float32)).all()
+    assert (v0["uv_y"] == (want["uv0"][:, 1].astype(np.float64) / 65535.0).astype(np.float32)).all()
+    assert (v0["color"] == (want["c0"].astype(np.float64) / 255.0).astype(np.float32)).all()
+    # defaults: normal (1, 0, 0) (then flipped: -0.0), uv 0, colour 1 (assets.cpp:995-1001); RGB colours get alpha 1
+    assert (v1["normal"] == np.array([1.0, 0.0, 0.0], np.float32)).all()
+    assert np.signbit(v1["normal"][:, 1]).all()
+    assert (v1["uv_x"] == 0).all() and (v1["uv_y"] == 0).all()
+    assert (v1["color"][:, :3] == want["c1"]).all() and (v1["color"][:, 3] == 1).all()
+    assert (v2["normal"] == _flip(np.maximum(want["nr2"].astype(np.float64) / 127.0, -1.0).astype(np.float32))).all()
+    assert (v2["uv_x"] == np.maximum(want["uv2"][:, 0].astype(np.float64) / 32767.0, -1.0).astype(np.float32)).all()
+    assert (v2["color"] == 1).all()
+    # bounds = AABB::create(min, max) of the flipped positions (assets.cpp:1061-1073, geometrytypes.hpp:26-33)
+    allp = _flip(np.concatenate([p0, p1, p2]))
+    lo, hi = allp.min(0), allp.max(0)
+    assert np.allclose(m.bounds[0], (lo + hi) * 0.5, rtol=1e-6, atol=1e-6)
+    assert np.allclose(m.bounds[1], (hi - lo) * 0.5, rtol=1e-6, atol=1e-6)
+    assert any("Triangles mode" in line for line in a.warnings)
+    assert any("missing material index" in line for line in a.warnings)
+
+
+def test_gltf_accessors_surfaces_and_conversions_in_every_container(tmp_path):
+    b, want = _two_primitive_asset()
+    # GLB from memory
+    _check_two_primitive_asset(assets.load_gltf_bytes(b.glb(), is_glb=True), want)
+    # GLB from a file: anything that is not ".gltf" is read as a binary container (assets.cpp:422-430)
+    (tmp_path / "thing.glb").write_bytes(b.glb())
+    _check_two_primitive_asset(assets.load_gltf(str(tmp_path / "thing.glb")), want)
+    (tmp_path / "thing.bin2").write_bytes(b.glb())
+    _check_two_primitive_asset(assets.load_gltf(str(tmp_path / "thing.bin2")), want)
+    # JSON with a base64 buffer
+    (tmp_path / "embedded.gltf").write_bytes(b.gltf_embedded())
+    _check_two_primitive_asset(assets.load_gltf(str(tmp_path / "embedded.gltf")), want)
+    # JSON with an external buffer whose name needs percent-decoding
+    doc, blob = b.gltf_external("my%20buffer.bin")
+    (tmp_path / "external.gltf").write_bytes(doc)
+    (tmp_path / "my buffer.bin").write_bytes(blob)
+    _check_two_primitive_asset(assets.load_gltf(str(tmp_path / "external.gltf")), want)
+
+
+def test_gltf_primitives_and_meshes_that_are_skipped():
+    b = gw.GltfBuilder()
+    p = np.eye(3, dtype=np.float32)
+    idx = np.array([0, 1, 2], np.uint16)
+    pa, ia = b.accessor(p), b.accessor(idx)
+    scalar = b.accessor(np.arange(3, dtype=np.float32))
+    b.doc["meshes"] = [
+        {"name": "no_indices", "primitives": [{"attributes": {"POSITION": pa}}]},
+        {"name": "no_position", "primitives": [{"attributes": {"NORMAL": pa}, "indices": ia}]},
+        {"name": "empty", "primitives": []},
+        {"name": "ok", "primitives": [{"attributes": {"POSITION": pa}, "indices": 99},  # accessor out of range
+                                      {"attributes": {"POSITION": scalar}, "indices": ia},  # POSITION is not VEC3
+                                      {"attributes": {"POSITION": pa, "NORMAL": scalar, "TEXCOORD_0": pa}, "indices": ia,
+                                       "material": 5}]},
+    ]
+    a = assets.load_gltf_bytes(b.glb(), is_glb=True)
+    # meshes without a usable primitive are not registered (assets.cpp:1056-1059); glTF order otherwise
+    assert [m.name for m in a.meshes] == ["mesh_ok"] and a.meshes[0].gltf_mesh_index == 3
+    m = a.meshes[0]
+    assert m.surfaces == [(0, 3, -1)] and len(m.vertices) == 3
+    assert (m.vertices["normal"] == np.array([1, 0, 0], np.float32)).all()  # unreadable NORMAL: default kept
+    text = "\n".join(a.warnings)
+    assert text.count("no valid indices accessor") == 2
+    assert "no valid vertices accessor" in text
+    assert "out of bounds material index" in text
+    assert "NORMAL cannot be read" in text and "TEXCOORD_0 cannot be read" in text
+
+
+def test_gltf_accessors_that_leave_their_buffer_are_refused():
+    for mutate in ["count", "offset", "view_length", "sparse_index"]:
+        b = gw.GltfBuilder()
+        p = np.arange(30, dtype=np.float32).reshape(10, 3)
+        idx = np.arange(9, dtype=np.uint32)
+        if mutate == "sparse_index":
+            pa = b.sparse_accessor(p, np.array([2, 11]), np.ones((2, 3), np.float32))  # element 11 of 10
+        else:
+            pa = b.accessor(p)
+        ia = b.accessor(idx)
+        if mutate == "count":
+            b.doc["accessors"][pa]["count"] = 11
+        elif mutate == "offset":
+            b.doc["accessors"][pa]["byteOffset"] = 4
+        elif mutate == "view_length":
+            b.doc["bufferViews"][b.doc["accessors"][ia]["bufferView"]]["byteLength"] = 1 << 20
+        b.doc["meshes"] = [{"name": "m", "primitives": [{"attributes": {"POSITION": pa}, "indices": ia}]}]
+        a = assets.load_gltf_bytes(b.glb(), is_glb=True)
+        assert a.meshes == [], mutate
+        assert any("cannot be read" in line for line in a.warnings), mutate
+
+
+def test_gltf_load_errors(tmp_path):
+    with pytest.raises(assets.AssetError, match="Unable to open file"):
+        assets.load_gltf(str(tmp_path / "missing.glb"))
+    (tmp_path / "empty.glb").write_bytes(b"")
+    with pytest.raises(assets.AssetError):
+        assets.load_gltf(str(tmp_path / "empty.glb"))
+    # the reference's own asset is a git-LFS pointer file: text, not a GLB container
+    (tmp_path / "sphere.glb").write_bytes(b"version https://git-lfs.github.com/spec/v1\noid sha256:00\nsize 1\n")
+    with pytest.raises(assets.AssetError, match="bad magic"):
+        assets.load_gltf(str(tmp_path / "sphere.glb"))
+    for text in [b"{", b"[1, 2]", b'{"meshes": []}', b'{"asset": {}}', b'{"asset": {"version": "2.0"}} trailing',
+                 b'{"asset": {"version": "2.0"}, "x": "\\q"}', b"[" * 1000]:
+        with pytest.raises(assets.AssetError):
+            assets.load_gltf_bytes(text, is_glb=False)
+    ok = assets.load_gltf_bytes('{"asset": {"version": "2.0"}, "extra": ["\\u00e9\\ud83d\\ude00", 1e3, -0.5, true, null]}'.encode(),
+                                is_glb=False)
+    assert ok.meshes == [] and ok.materials == []
+    glb = gw.GltfBuilder().glb()
+    for bad in [glb[:10], b"glTX" + glb[4:], glb[:4] + (1).to_bytes(4, "little") + glb[8:], glb[:12] + (1 << 30).to_bytes(4, "little") + glb[16:]]:
+        with pytest.raises(assets.AssetError):
+            assets.load_gltf_bytes(bad, is_glb=True)
+    # random corruption of a valid file never crashes
+    b, _ = _two_primitive_asset()
+    data = b.glb()
+    rng = np.random.default_rng(1)
+    for k in range(300):
+        mutated = bytearray(data)
+        for _ in range(1 + k % 4):
+            mutated[int(rng.integers(0, len(mutated)))] = int(rng.integers(0, 256))
+        try:
+            assets.load_gltf_bytes(bytes(mutated), is_glb=True)
+        except assets.AssetError:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# materials
+# ---------------------------------------------------------------------------------------------------------------
+def _images(seed):
+    rng = np.random.default_rng(seed)
+    return {k: rng.integers(0, 256, (h, w, 4), dtype=np.uint8) for k, (w, h) in
+            {"color": (8, 4), "normal": (5, 5), "mr": (16, 2), "occ": (3, 7)}.items()}
+
+
+def test_gltf_material_maps_and_channel_overrides(tmp_path):
+    img = _images(3)
+    b = gw.GltfBuilder()
+    (tmp_path / "tex dir").mkdir()
+    (tmp_path / "tex dir" / "normal map.png").write_bytes(gw.png_rgba8(img["normal"]))
+    i_color = b.image_uri(gw.data_uri_png(gw.png_rgba8(img["color"])), name="albedo")
+    i_normal = b.image_uri("tex%20dir/normal%20map.png")
+    i_mr = b.image_uri(gw.data_uri_png(gw.png_rgba8(img["mr"])))
+    i_occ = b.image_uri(gw.data_uri_png(gw.png_rgba8(img["occ"])))
+    i_missing = b.image_uri("nowhere.png")
+    i_jpeg = b.image_uri("data:image/jpeg;base64,/9j/4AAQSkZJRgABAQ==")
+    t = {k: b.texture(i) for k, i in [("color", i_color), ("normal", i_normal), ("mr", i_mr), ("occ", i_occ),
+                                     ("missing", i_missing), ("jpeg", i_jpeg)]}
+    b.doc["textures"].append({"name": "dangling"})  # no source
+    b.doc["materials"] = [
+        {"name": "full", "pbrMetallicRoughness": {"baseColorTexture": {"index": t["color"]},
+                                                  "metallicRoughnessTexture": {"index": t["mr"]}},
+         "normalTexture": {"index": t["normal"]}, "occlusionTexture": {"index": t["occ"]}},
+        {"name": "packed", "pbrMetallicRoughness": {"metallicRoughnessTexture": {"index": t["mr"]}},
+         "occlusionTexture": {"index": t["mr"]}},
+        {"name": "occlusion_only", "occlusionTexture": {"index": t["occ"]}},
+        {"name": "bare"},
+        {"name": "broken", "pbrMetallicRoughness": {"baseColorTexture": {"index": t["missing"]},
+                                                    "metallicRoughnessTexture": {"index": 6}},
+         "normalTexture": {"index": t["jpeg"]}, "occlusionTexture": {"index": 99}},
+    ]
+    (tmp_path / "materials.gltf").write_bytes(json.dumps(b.document()).encode().replace(b'"buffers": [{"byteLength": 0}]', b'"buffers": []'))
+    a = assets.load_gltf(str(tmp_path / "materials.gltf"))
+    assert [m["name"] for m in a.materials] == ["full", "packed", "occlusion_only", "bare", "broken"]
+    full, packed, occ_only, bare, broken = a.materials
+
+    # colour maps are sRGB, the others UNORM (assets.cpp:706-715); names: image name, else material_index_kind
+    assert (full["color"][0] == img["color"]).all() and full["color"][1] is True
+    assert (full["normal"][0] == img["normal"]).all() and full["normal"][1] is False
+    assert full["texture_names"] == {"color": "texture_albedo", "normal": f"texture_full_{t['normal']}_normal",
+                                     "orm": f"texture_full_{t['mr']}_orm"}
+    # ORM = the metallicRoughness image with R := 255 (assets.cpp:778-782) ...
+    want = img["mr"].copy()
+    want[..., 0] = 255
+    assert (full["orm"][0] == want).all() and (packed["orm"][0] == want).all() and full["orm"][1] is False
+    # ... or, without one, the occlusion image with G := B := 0 (:783-788)
+    want = img["occ"].copy()
+    want[..., 1:3] = 0
+    assert (occ_only["orm"][0] == want).all()
+    assert occ_only["color"] is None and occ_only["normal"] is None
+    assert bare["color"] is None and bare["normal"] is None and bare["orm"] is None
+    # every failure keeps the default map (assets.cpp:756 + the warnings at :803, :833, :859)
+    assert broken["color"] is None and broken["normal"] is None and broken["orm"] is None
+    text = "\n".join(a.warnings)
+    assert "Material full: occlusion and roughnessMetallic textures differ" in text
+    assert "Material packed: occlusion and roughnessMetallic" not in text
+    assert "Material bare: Missing color texture." in text and "Material bare: Missing metallicRoughness texture" in text
+    assert "does not result in a valid file path. URI was: nowhere.png" in text
+    assert "stbi: Failed to convert image." in text
+    assert "was missing imageIndex" in text and "Out of bounds texture index." not in text  # index 6 exists but has no source
+    for kind in ("ORM", "color", "normal"):
+        assert f"Material broken: Failed to upload {kind} texture." in text
+    # the material a surface gets: maps from the file, defaults for the rest
+    resolved = a.material(2)
+    assert (resolved["orm"][0] == want).all()
+    assert (resolved["color"][0] == meshes.default_color_map()).all() and (resolved["normal"][0][..., :3] == (127, 127, 255)).all()
+    assert a.material(-1) is a.default_material()
+
+
+def test_gltf_buffer_view_images_follow_the_reference_unless_asked():
+    img = _images(9)["color"]
+    b = gw.GltfBuilder()
+    tex = b.texture(b.image_view(gw.png_rgba8(img), name="embedded"))
+    b.doc["materials"] = [{"name": "m", "pbrMetallicRoughness": {"baseColorTexture": {"index": tex}}}]
+    # the reference handles byte-array and URI sources only (assets.cpp:482-548): GLB-embedded images keep the default map
+    a = assets.load_gltf_bytes(b.glb(), is_glb=True)
+    assert a.materials[0]["color"] is None
+    assert any("Unsupported glTF image source found." in line for line in a.warnings)
+    a = assets.load_gltf_bytes(b.glb(), is_glb=True, flags=abi.SZG_GLTF_DECODE_BUFFER_VIEW_IMAGES)
+    assert (a.materials[0]["color"][0] == img).all() and a.materials[0]["texture_names"]["color"] == "texture_embedded"
+
+
+def test_default_material_maps_are_the_asset_library_defaults():
+    # assets.cpp:1294-1398, regenerated independently in syzygy_amd/meshes.py
+    d = meshes.default_material()
+    assert (assets.default_material_map(abi.SZG_MAP_COLOR) == d["color"][0]).all()
+    assert (assets.default_material_map(abi.SZG_MAP_NORMAL) == d["normal"][0]).all()
+    assert (assets.default_material_map(abi.SZG_MAP_ORM) == d["orm"][0]).all()
+    with pytest.raises(assets.AssetError):
+        assets.default_material_map(3)
+
+
+def test_sphere_asset_is_outward_facing_after_the_flip():
+    """The reference's shipped asset is a sphere (assets/sphere.glb, an LFS pointer here): an equivalent one is written,
+    loaded, and must come out clockwise-front in engine space (+y down) as the raster state expects (deferred.cpp:380)."""
+    pos, nrm, uv, idx = gw.uv_sphere(8, 16)
+    tri = pos[idx.reshape(-1, 3)]
+    face = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    keep = np.linalg.norm(face, axis=1) > 1e-9
+    assert ((face * tri.mean(1)).sum(-1)[keep] > 0).all()  # glTF: counter-clockwise seen from outside
+    b = gw.GltfBuilder()
+    b.doc["meshes"] = [{"name": "Sphere", "primitives": [{"attributes": {"POSITION": b.accessor(pos), "NORMAL": b.accessor(nrm),
+                                                                        "TEXCOORD_0": b.accessor(uv)},
+                                                          "indices": b.accessor(idx.astype(np.uint16))}]}]
+    a = assets.load_gltf_bytes(b.glb(), is_glb=True)
+    m = a.meshes[0]
+    tri = m.vertices["position"][m.indices.reshape(-1, 3)]
+    face = np.cross(tri[:, 1] - tri[:, 0], tri[:, 2] - tri[:, 0])
+    assert ((face * tri.mean(1)).sum(-1)[keep] < 0).all()  # mirrored: clockwise seen from outside
+    assert (np.einsum("ij,ij->i", m.vertices["normal"], m.vertices["position"]) > 0.99).all()  # normals still point outwards
+    assert np.allclose(m.bounds[0], 0, atol=1e-6) and np.allclose(m.bounds[1], 1, atol=1e-6)

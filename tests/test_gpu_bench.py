@@ -47,3 +47,17 @@ def test_example_frame_loop_runs():
     assert "ms per frame" in r.stdout
     value = float(r.stdout.split("mean display value")[1].split()[0])
     assert 0.02 < value < 0.98
+
+
+def test_example_render_gltf_runs(tmp_path):
+    """examples/render_gltf.py: a GLB written to disk -> include/szg/assets.h loader -> the whole path, one frame."""
+    out = tmp_path / "gltf.ppm"
+    r = subprocess.run([sys.executable, "examples/render_gltf.py", "--width", "320", "--height", "180", "--out", str(out)],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "1 meshes, 1 materials" in r.stdout and "[warning]" in r.stdout  # the sphere has no occlusion texture
+    covered = float(r.stdout.split("geometry covers")[1].split("%")[0])
+    assert 20.0 < covered < 95.0
+    value = float(r.stdout.split("mean display value")[1].split()[0])
+    assert 0.02 < value < 0.98
+    assert out.stat().st_size > 320 * 180 * 3
