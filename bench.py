@@ -286,6 +286,13 @@ def main():
             roofline_valu = {"bound": "valu-issue", "kernel": "k_composite", "achieved": achieved, "peak": peak,
                              "unit": "G wave64-instructions/s", "frac": achieved / peak,
                              "instructions_per_launch": v["SQ_INSTS_VALU_per_launch"], "source": "profiles/r01_pmc_composite.json"}
+            if "instruction_classes_per_launch" in v:
+                # the same bound with every instruction class priced at its own measured issue cost (transcendentals 8.5
+                # cycles, min/max/select/floor 4.4, ...) instead of the 3.1 cycles of a pure fma stream
+                cycles = sum(n * v["class_issue_cycles"][c] for c, n in v["instruction_classes_per_launch"].items())
+                floor_s = cycles / (v["simds"] * v["clock_GHz"] * 1e9)
+                roofline_valu["mix_weighted_floor_ms"] = floor_s * 1e3
+                roofline_valu["frac_of_mix_weighted_ceiling"] = floor_s / comp_s
         except Exception:
             pass
     frame_bytes = bytes_composite + bytes_lights + bytes_luts
