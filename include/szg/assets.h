@@ -20,11 +20,17 @@
  * The parsing itself is third-party code in the reference and NOT under /root/reference: fastgltf (glTF, base64, accessor
  * tools; cmake/dependencies.cmake) and stb_image (image decoding, thirdparty include). Their published behaviour is
  * restated: glTF 2.0 accessors (all component types, `normalized`, byteStride, sparse), GLB containers, data: URIs;
- * PNG decoding as stb_image does it for a 4-channel request (bit depths 1-16, all colour types, tRNS, Adam7; 16-bit
- * samples keep their high byte; gamma chunks ignored; checksums not verified). JPEG and stb_image's other formats are
- * NOT decoded: such an image fails like any undecodable image does in the reference (warning, default map kept).
+ * the two image encodings glTF 2.0 allows, decoded as stb_image does for a 4-channel request:
+ *   PNG   bit depths 1-16, all colour types, tRNS, Adam7; 16-bit samples keep their high byte; gamma chunks ignored;
+ *         checksums not verified
+ *   JPEG  baseline / extended-sequential Huffman, 8 bit, grey or three components with any sampling factors, restart
+ *         intervals, interleaved or per-component scans; stb_image's integer inverse DCT, triangle-filter chroma
+ *         upsampling and fixed-point YCbCr conversion (syzygy_amd/csrc/host_jpeg.cpp). Progressive, arithmetic-coded,
+ *         12-bit and CMYK files are NOT decoded.
+ * An image that is not decoded fails like any undecodable image does in the reference (warning, default map kept).
  * The reference holds no usable asset for this path (assets/sphere.glb is a 132-byte LFS pointer): parity unpinned;
- * tests write glTF/GLB/PNG files with an independent Python encoder and compare array by array.
+ * tests write glTF/GLB/PNG/JPEG files with independent Python encoders and compare array by array (JPEG: against a
+ * numpy restatement of the same published arithmetic).
  *
  * Where the reference would read out of bounds or trips an assert (accessor past its buffer, attribute longer than
  * POSITION, wrong accessor type) this loader skips the item with a warning instead; every such case is listed in
@@ -110,7 +116,7 @@ const char* szg_gltf_warnings(const szg_gltf* asset);
 #define SZG_DEFAULT_MAP_DIMENSIONS 64
 int szg_default_material_map(int kind, uint8_t* rgba);
 
-/* detail_stbi::loadRGBA (assets.cpp:319-364): PNG bytes -> RGBA8. The caller frees *out_rgba with szg_free_rgba. */
+/* detail_stbi::loadRGBA (assets.cpp:319-364): PNG or JPEG bytes -> RGBA8. The caller frees *out_rgba with szg_free_rgba. */
 int szg_decode_image_rgba(const void* bytes, size_t size, uint32_t* out_width, uint32_t* out_height, uint8_t** out_rgba);
 void szg_free_rgba(uint8_t* rgba);
 

@@ -858,12 +858,24 @@ class Inflater
 uint32_t be32(const uint8_t* p) { return (uint32_t{p[0]} << 24) | (uint32_t{p[1]} << 16) | (uint32_t{p[2]} << 8) | uint32_t{p[3]}; }
 uint32_t be16(const uint8_t* p) { return (uint32_t{p[0]} << 8) | uint32_t{p[1]}; }
 
+bool decodePng(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, Bytes& rgba, std::string& why);
+
+// detail_stbi::loadRGBA (assets.cpp:319-364): the two encodings glTF 2.0 allows, told apart by their signatures
+bool decodeImageBytes(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, Bytes& rgba, std::string& why)
+{
+    if (size >= 2 && data[0] == 0xFF && data[1] == 0xD8)
+    {
+        return szg::decode_jpeg(data, size, width, height, rgba, why);
+    }
+    return decodePng(data, size, width, height, rgba, why);
+}
+
 bool decodePng(const uint8_t* data, size_t size, uint32_t& width, uint32_t& height, Bytes& rgba, std::string& why)
 {
     static const uint8_t signature[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (size < 8 || std::memcmp(data, signature, 8) != 0)
     {
-        why = "not a PNG (the only image encoding this build decodes)";
+        why = "neither a PNG nor a JPEG (the image encodings this build decodes)";
         return false;
     }
     size_t at = 8;
@@ -1597,7 +1609,7 @@ class Loader
             return false;
         }
         std::string why;
-        if (!decodePng(bytes.data(), bytes.size(), d.width, d.height, d.rgba, why))
+        if (!decodeImageBytes(bytes.data(), bytes.size(), d.width, d.height, d.rgba, why))
         {
             warn("stbi: Failed to convert image. (" + what + ": " + why + ")");
             warn("Failed to load image from glTF.");
@@ -2106,7 +2118,7 @@ int szg_decode_image_rgba(const void* bytes, size_t size, uint32_t* out_width, u
     {
         Bytes rgba;
         std::string why;
-        if (!decodePng(static_cast<const uint8_t*>(bytes), size, *out_width, *out_height, rgba, why))
+        if (!decodeImageBytes(static_cast<const uint8_t*>(bytes), size, *out_width, *out_height, rgba, why))
         {
             szg::set_last_error(("stbi: Failed to convert image. (" + why + ")").c_str());
             return SZG_ERR_PARSE;

@@ -12,6 +12,7 @@ import pytest
 
 from syzygy_amd import abi, assets, meshes
 from tests import gltf_writer as gw
+from tests import jpeg_tools as jt
 
 
 def _expand_to_rgba8(samples, color_type, depth, palette=None, trns=None):
@@ -120,6 +121,78 @@ def test_png_rejects_what_it_cannot_decode():
             assets.decode_image_rgba(bytes(mutated))
         except assets.AssetError:
             pass
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# JPEG (the other image encoding of glTF 2.0): C++ decoder == the numpy restatement of stb_image's arithmetic
+# ---------------------------------------------------------------------------------------------------------------
+def _picture(w, h, seed):
+    rng = np.random.default_rng(seed)
+    y, x = np.mgrid[0:h, 0:w]
+    img = np.stack([(x * 5 + seed) % 256, (y * 7) % 256, ((x + y) * 3) % 256], -1).astype(np.uint8)
+    if w > 12 and h > 12:
+        img[h // 4 : h // 2, w // 4 : w // 2] = rng.integers(0, 256, (h // 2 - h // 4, w // 2 - w // 4, 3))
+        img[h // 2 :, : w // 3] = (40, 200, 90)
+    return img
+
+
+SAMPLINGS = {"444": ((1, 1),) * 3, "420": ((2, 2), (1, 1), (1, 1)), "422": ((2, 1), (1, 1), (1, 1)), "440": ((1, 2), (1, 1), (1, 1)),
+             "411": ((4, 1), (1, 1), (1, 1)), "mixed": ((2, 2), (2, 1), (1, 2)), "410": ((4, 2), (1, 1), (1, 1))}
+
+
+@pytest.mark.parametrize("sampling", sorted(SAMPLINGS))
+@pytest.mark.parametrize("restart,interleaved", [(0, True), (2, True), (5, False)])
+def test_jpeg_baseline_sampling_restart_and_scan_layouts(sampling, restart, interleaved):
+    for k, (w, h) in enumerate([(37, 53), (16, 16), (1, 1), (9, 40), (64, 7)]):
+        img = _picture(w, h, k)
+        data = jt.encode(img, sampling=SAMPLINGS[sampling], quality=[90, 60, 97, 75, 35][k], restart=restart, interleaved=interleaved)
+        got = assets.decode_image_rgba(data)
+        want = jt.decode(data)
+        assert got.shape == (h, w, 4) and (got == want).all(), (sampling, w, h)
+        assert (got[..., 3] == 255).all()
+    # and the decoded picture is the picture (within what 4:4:4 at quality 97 loses)
+    img = _picture(48, 40, 9)
+    got = assets.decode_image_rgba(jt.encode(img, sampling=SAMPLINGS["444"], quality=97))
+    assert np.abs(got[..., :3].astype(int) - img.astype(int)).mean() < 2.0
+
+
+def test_jpeg_colour_spaces_and_table_precisions():
+    img = _picture(41, 23, 4)
+    grey = img[..., 1]
+    for data in [jt.encode(grey, sampling=[(1, 1)]), jt.encode(grey, sampling=[(2, 2)], restart=1),  # a lone component: sampling factors are moot
+                 jt.encode(img, rgb_ids=True, sampling=SAMPLINGS["444"]),  # components named R, G, B: stored as they are
+                 jt.encode(img, adobe_transform=0, sampling=SAMPLINGS["444"]),  # Adobe marker, transform 0: RGB
+                 jt.encode(img, adobe_transform=1),  # Adobe marker, transform 1: YCbCr
+                 jt.encode(img, jfif=False),  # bare YCbCr
+                 jt.encode(img, q16=True, comment=b"16-bit luma quantisation table"),
+                 jt.encode(img, quality=100), jt.encode(img, quality=5)]:
+        got = assets.decode_image_rgba(data)
+        assert (got == jt.decode(data)).all()
+    rgb = assets.decode_image_rgba(jt.encode(img, rgb_ids=True, sampling=SAMPLINGS["444"], quality=97))
+    assert np.abs(rgb[..., :3].astype(int) - img.astype(int)).mean() < 2.0
+    g = assets.decode_image_rgba(jt.encode(grey, sampling=[(1, 1)], quality=97))
+    assert (g[..., 0] == g[..., 1]).all() and (g[..., 1] == g[..., 2]).all()
+    assert np.abs(g[..., 0].astype(int) - grey.astype(int)).mean() < 2.0
+
+
+def test_jpeg_what_is_refused_and_what_is_tolerated():
+    img = _picture(33, 17, 2)
+    data = jt.encode(img, restart=2)
+    sof = data.index(b"\xff\xc0")
+    for bad, why in [(data[:sof] + b"\xff\xc2" + data[sof + 2 :], "progressive"), (data[:sof] + b"\xff\xc9" + data[sof + 2 :], "arithmetic"),
+                     (data[: sof + 4] + b"\x0c" + data[sof + 5 :], "8-bit"), (data[:2] + data[sof:], "not defined"),
+                     (data[:sof] + data[sof + 19 :], "frame header"), (b"\xff\xd8\xff\xd9", "without image data")]:
+        with pytest.raises(assets.AssetError, match=why):
+            assets.decode_image_rgba(bad)
+    # a file cut short still decodes (stb_image feeds zeros past the end): the rows before the cut are intact
+    tall = jt.encode(_picture(33, 90, 3), restart=2)
+    whole = assets.decode_image_rgba(tall)
+    cut = assets.decode_image_rgba(tall[: len(tall) - (len(tall) - tall.index(b"\xff\xda")) // 4])
+    assert cut.shape == whole.shape and (cut[:16] == whole[:16]).all() and not (cut == whole).all()
+    whole = assets.decode_image_rgba(data)
+    # garbage between segments and fill bytes before a marker are skipped
+    noisy = data[:2] + b"\x00\x11" + data[2:sof] + b"\xff\xff" + data[sof:]
+    assert (assets.decode_image_rgba(noisy) == whole).all()
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -330,7 +403,7 @@ def test_gltf_material_maps_and_channel_overrides(tmp_path):
     i_mr = b.image_uri(gw.data_uri_png(gw.png_rgba8(img["mr"])))
     i_occ = b.image_uri(gw.data_uri_png(gw.png_rgba8(img["occ"])))
     i_missing = b.image_uri("nowhere.png")
-    i_jpeg = b.image_uri("data:image/jpeg;base64,/9j/4AAQSkZJRgABAQ==")
+    i_jpeg = b.image_uri("data:image/jpeg;base64,/9j/4AAQSkZJRgABAQ==")  # a JPEG header and nothing else
     t = {k: b.texture(i) for k, i in [("color", i_color), ("normal", i_normal), ("mr", i_mr), ("occ", i_occ),
                                      ("missing", i_missing), ("jpeg", i_jpeg)]}
     b.doc["textures"].append({"name": "dangling"})  # no source
@@ -382,6 +455,25 @@ def test_gltf_material_maps_and_channel_overrides(tmp_path):
     assert (resolved["orm"][0] == want).all()
     assert (resolved["color"][0] == meshes.default_color_map()).all() and (resolved["normal"][0][..., :3] == (127, 127, 255)).all()
     assert a.material(-1) is a.default_material()
+
+
+def test_gltf_material_with_jpeg_maps(tmp_path):
+    img = _picture(24, 16, 6)
+    jpeg = jt.encode(img, quality=92)
+    (tmp_path / "base.jpg").write_bytes(jpeg)
+    b = gw.GltfBuilder()
+    import base64
+    t_file = b.texture(b.image_uri("base.jpg"))
+    t_data = b.texture(b.image_uri("data:image/jpeg;base64," + base64.b64encode(jpeg).decode()))
+    b.doc["materials"] = [{"name": "photo", "pbrMetallicRoughness": {"baseColorTexture": {"index": t_file},
+                                                                     "metallicRoughnessTexture": {"index": t_data}}}]
+    (tmp_path / "m.gltf").write_bytes(json.dumps(b.document()).encode().replace(b'"buffers": [{"byteLength": 0}]', b'"buffers": []'))
+    a = assets.load_gltf(str(tmp_path / "m.gltf"))
+    want = jt.decode(jpeg)
+    assert (a.materials[0]["color"][0] == want).all() and a.materials[0]["color"][1] is True
+    orm = want.copy()
+    orm[..., 0] = 255
+    assert (a.materials[0]["orm"][0] == orm).all()
 
 
 def test_gltf_buffer_view_images_follow_the_reference_unless_asked():
