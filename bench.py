@@ -380,6 +380,23 @@ def main():
         f2.record()
         torch.cuda.synchronize()
         aerial_ms, fast_ms = f0.elapsed_time(f1) / reps, f1.elapsed_time(f2) / reps
+        # BASELINE.json names "all 4 LUTs": the reference has neither a multi-scatter nor an aerial-perspective LUT pass
+        # (SURVEY a17 / a18), so the exact frame computes two LUTs and `value` times exactly the reference's four passes.
+        # What the frame costs when the other two LUTs are computed as well (no pixel changes: the exact composite does
+        # not read them) is stated here.
+        sky.recordMultiScatterLUT(None, 0, atmospheres)
+        torch.cuda.synchronize()
+        m0, m1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        m0.record()
+        for _ in range(reps):
+            sky.recordMultiScatterLUT(None, 0, atmospheres)
+        m1.record()
+        torch.cuda.synchronize()
+        multi_ms = m0.elapsed_time(m1) / reps
+        frame4 = elapsed / args.steps * 1e3 + multi_ms + aerial_ms
+        out["all_four_luts"] = {"in_value": False, "multiscatter_lut_ms": multi_ms, "aerial_lut_ms": aerial_ms,
+                                "frame_ms_with_all_four_luts": frame4, "mpixels_per_s_with_all_four_luts": W * H / frame4 / 1e3,
+                                "note": "exact frame + the two LUT passes the reference does not have (opt-in extensions)"}
         out["fast_composite_extension"] = {
             "approximate": True, "in_value": False, "aerial_lut_ms": aerial_ms, "composite_fast_ms": fast_ms,
             "achieved_GBps": bytes_composite / (fast_ms / 1e3) / 1e9, "frac_of_8TBps": bytes_composite / (fast_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
