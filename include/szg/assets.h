@@ -116,6 +116,14 @@ const char* szg_gltf_warnings(const szg_gltf* asset);
 #define SZG_DEFAULT_MAP_DIMENSIONS 64
 int szg_default_material_map(int kind, uint8_t* rgba);
 
+/* AssetLibrary's built-in meshes (assets.cpp:1400-1472 "mesh_Plane": a 2 x 2 quad in the xz plane facing -y; :1474-1610
+ * "mesh_Cube": 2 x 2 x 2, four vertices per face, every face with the full uv square), one surface each with the default
+ * material (-1). The cube's vertices are built without a colour (assets.cpp:1484-1507): value-initialised, (0, 0, 0, 0);
+ * no shader reads the vertex colour. The arrays live in the library. */
+#define SZG_DEFAULT_MESH_CUBE 0
+#define SZG_DEFAULT_MESH_PLANE 1
+int szg_default_mesh(int kind, szg_asset_mesh* out);
+
 /* detail_stbi::loadRGBA (assets.cpp:319-364): PNG or JPEG bytes -> RGBA8. The caller frees *out_rgba with szg_free_rgba. */
 int szg_decode_image_rgba(const void* bytes, size_t size, uint32_t* out_width, uint32_t* out_height, uint8_t** out_rgba);
 void szg_free_rgba(uint8_t* rgba);

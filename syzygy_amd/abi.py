@@ -409,6 +409,7 @@ SZG_ERR_PARSE = -7
 SZG_GLTF_DECODE_BUFFER_VIEW_IMAGES = 1
 SZG_MAP_COLOR, SZG_MAP_NORMAL, SZG_MAP_ORM = 0, 1, 2
 SZG_DEFAULT_MAP_DIMENSIONS = 64
+SZG_DEFAULT_MESH_CUBE, SZG_DEFAULT_MESH_PLANE = 0, 1
 
 
 class AssetTexture(C.Structure):
@@ -447,6 +448,7 @@ ASSET_FUNCTIONS = {
     "szg_gltf_material": (C.c_int, [VP, U32, P(AssetMaterial)]),
     "szg_gltf_warnings": (C.c_char_p, [VP]),
     "szg_default_material_map": (C.c_int, [C.c_int, P(C.c_uint8)]),
+    "szg_default_mesh": (C.c_int, [C.c_int, P(AssetMesh)]),
     "szg_decode_image_rgba": (C.c_int, [VP, C.c_size_t, P(U32), P(U32), P(P(C.c_uint8))]),
     "szg_free_rgba": (None, [P(C.c_uint8)]),
 }

@@ -30,7 +30,7 @@ def default_material_map(kind):
 
 
 def decode_image_rgba(data):
-    """detail_stbi::loadRGBA (assets.cpp:319-364): encoded image bytes -> uint8 [h, w, 4]. PNG only."""
+    """detail_stbi::loadRGBA (assets.cpp:319-364): encoded image bytes -> uint8 [h, w, 4]. PNG or baseline JPEG."""
     data = bytes(data)
     w, h, ptr = abi.U32(), abi.U32(), C.POINTER(C.c_uint8)()
     buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
@@ -83,6 +83,26 @@ class GltfAsset:
         return meshes.MeshInstanced(m.vertices, m.indices, surfaces, models, name=m.name, **kwargs)
 
 
+def default_mesh(kind):
+    """AssetLibrary::defaultMesh (assets.cpp:1668-1676): the built-in cube (abi.SZG_DEFAULT_MESH_CUBE) or plane as a GltfMesh."""
+    m = abi.AssetMesh()
+    if lib().szg_default_mesh(int(kind), C.byref(m)) != abi.SZG_OK:
+        raise AssetError(_last_error())
+    return _mesh(m)
+
+
+def _mesh(m):
+    vertices = np.zeros(m.vertex_count, abi.VERTEX_DTYPE)
+    if m.vertex_count:
+        C.memmove(vertices.ctypes.data, m.vertices, vertices.nbytes)
+    indices = np.zeros(m.index_count, np.uint32)
+    if m.index_count:
+        C.memmove(indices.ctypes.data, m.indices, indices.nbytes)
+    surfaces = [(m.surfaces[k].first_index, m.surfaces[k].index_count, m.surfaces[k].material) for k in range(m.surface_count)]
+    bounds = (np.array(m.vertex_bounds.center, np.float32), np.array(m.vertex_bounds.half_extent, np.float32))
+    return GltfMesh((m.name or b"").decode(errors="replace"), vertices, indices, surfaces, bounds, m.gltf_mesh_index)
+
+
 def _texture(t):
     if not t.rgba:
         return None
@@ -106,15 +126,7 @@ def _collect(handle):
         m = abi.AssetMesh()
         if L.szg_gltf_mesh(handle, i, C.byref(m)) != abi.SZG_OK:
             raise AssetError(_last_error())
-        vertices = np.zeros(m.vertex_count, abi.VERTEX_DTYPE)
-        if m.vertex_count:
-            C.memmove(vertices.ctypes.data, m.vertices, vertices.nbytes)
-        indices = np.zeros(m.index_count, np.uint32)
-        if m.index_count:
-            C.memmove(indices.ctypes.data, m.indices, indices.nbytes)
-        surfaces = [(m.surfaces[k].first_index, m.surfaces[k].index_count, m.surfaces[k].material) for k in range(m.surface_count)]
-        bounds = (np.array(m.vertex_bounds.center, np.float32), np.array(m.vertex_bounds.half_extent, np.float32))
-        out_meshes.append(GltfMesh((m.name or b"").decode(errors="replace"), vertices, indices, surfaces, bounds, m.gltf_mesh_index))
+        out_meshes.append(_mesh(m))
     warnings = L.szg_gltf_warnings(handle).decode(errors="replace").splitlines()
     return GltfAsset(out_meshes, out_materials, warnings)
 

@@ -2106,6 +2106,109 @@ int szg_default_material_map(int kind, uint8_t* rgba)
     return SZG_OK;
 }
 
+int szg_default_mesh(int kind, szg_asset_mesh* out)
+{
+    if (out == nullptr || (kind != SZG_DEFAULT_MESH_CUBE && kind != SZG_DEFAULT_MESH_PLANE))
+    {
+        szg::set_last_error("szg_default_mesh: NULL output or unknown kind");
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    struct Builtin
+    {
+        std::vector<szg_vertex_packed> vertices;
+        std::vector<uint32_t> indices;
+        szg_asset_surface surface{};
+        szg_aabb bounds{};
+    };
+    static const Builtin builtins[2] = {
+        [] {
+            // assets.cpp:1476-1570: addCubeFace(uvOrigin, uvX, uvY, normal), six times
+            struct Face
+            {
+                float o[3], ex[3], ey[3], n[3];
+            };
+            static const Face faces[6] = {{{-1, -1, 1}, {2, 0, 0}, {0, 0, -2}, {0, -1, 0}}, {{-1, 1, -1}, {2, 0, 0}, {0, 0, 2}, {0, 1, 0}},
+                                          {{1, -1, -1}, {0, 0, 2}, {0, 2, 0}, {1, 0, 0}},   {{-1, -1, 1}, {0, 0, -2}, {0, 2, 0}, {-1, 0, 0}},
+                                          {{-1, -1, -1}, {2, 0, 0}, {0, 2, 0}, {0, 0, -1}}, {{1, -1, 1}, {-2, 0, 0}, {0, 2, 0}, {0, 0, 1}}};
+            Builtin b;
+            for (Face const& f : faces)
+            {
+                uint32_t const start = static_cast<uint32_t>(b.vertices.size());
+                static const float corner[4][2] = {{0, 0}, {1, 0}, {1, 1}, {0, 1}};
+                for (auto const& c : corner)
+                {
+                    szg_vertex_packed v{};
+                    for (int k = 0; k < 3; k++)
+                    {
+                        // uvOrigin, uvOrigin + uvX, uvOrigin + uvX + uvY, uvOrigin + uvY: sums of small integers, exact
+                        v.position[k] = f.o[k] + c[0] * f.ex[k] + c[1] * f.ey[k];
+                        v.normal[k] = f.n[k];
+                    }
+                    v.uv_x = c[0];
+                    v.uv_y = c[1];
+                    b.vertices.push_back(v);
+                }
+                for (uint32_t i : {0u, 1u, 2u, 0u, 2u, 3u})
+                {
+                    b.indices.push_back(start + i);
+                }
+            }
+            return b;
+        }(),
+        [] {
+            // assets.cpp:1401-1434
+            Builtin b;
+            static const float corner[4][4] = {{-1, 1, 0, 0}, {1, 1, 1, 0}, {1, -1, 1, 1}, {-1, -1, 0, 1}};
+            for (auto const& c : corner)
+            {
+                szg_vertex_packed v{};
+                v.position[0] = c[0];
+                v.position[1] = 0.0f;
+                v.position[2] = c[1];
+                v.uv_x = c[2];
+                v.uv_y = c[3];
+                v.normal[1] = -1.0f;
+                v.color[0] = v.color[1] = v.color[2] = v.color[3] = 1.0f;
+                b.vertices.push_back(v);
+            }
+            b.indices = {0, 1, 3, 1, 2, 3};
+            return b;
+        }()};
+    static const bool boundsDone = [] {
+        for (Builtin const& bc : builtins)
+        {
+            Builtin& b = const_cast<Builtin&>(bc);
+            float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+            float hi[3] = {std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest()};
+            for (szg_vertex_packed const& v : b.vertices)
+            {
+                for (int k = 0; k < 3; k++)
+                {
+                    lo[k] = v.position[k] < lo[k] ? v.position[k] : lo[k];
+                    hi[k] = v.position[k] > hi[k] ? v.position[k] : hi[k];
+                }
+            }
+            szg_aabb_create(lo, hi, &b.bounds);
+            b.surface.first_index = 0;
+            b.surface.index_count = static_cast<uint32_t>(b.indices.size());
+            b.surface.material = -1;
+        }
+        return true;
+    }();
+    (void)boundsDone;
+    Builtin const& b = builtins[kind];
+    out->name = kind == SZG_DEFAULT_MESH_CUBE ? "mesh_Cube" : "mesh_Plane";
+    out->vertices = b.vertices.data();
+    out->vertex_count = static_cast<uint32_t>(b.vertices.size());
+    out->indices = b.indices.data();
+    out->index_count = static_cast<uint32_t>(b.indices.size());
+    out->surfaces = &b.surface;
+    out->surface_count = 1;
+    out->vertex_bounds = b.bounds;
+    out->gltf_mesh_index = -1;
+    return SZG_OK;
+}
+
 int szg_decode_image_rgba(const void* bytes, size_t size, uint32_t* out_width, uint32_t* out_height, uint8_t** out_rgba)
 {
     if (bytes == nullptr || out_width == nullptr || out_height == nullptr || out_rgba == nullptr)

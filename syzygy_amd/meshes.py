@@ -44,13 +44,13 @@ def default_material():
     }
 
 
-def _vertices(rows):
+def _vertices(rows, color=(1.0, 1.0, 1.0, 1.0)):
     v = np.zeros(len(rows), abi.VERTEX_DTYPE)
     for i, (pos, uv, nrm) in enumerate(rows):
         v[i]["position"] = pos
         v[i]["uv_x"], v[i]["uv_y"] = uv
         v[i]["normal"] = nrm
-        v[i]["color"] = (1.0, 1.0, 1.0, 1.0)
+        v[i]["color"] = color
     return v
 
 
@@ -62,7 +62,8 @@ def plane_mesh():
 
 
 def cube_mesh():
-    """A 2x2x2 cube, four vertices per face, every face with the full uv square (assets.cpp:1474-1570)."""
+    """A 2x2x2 cube, four vertices per face, every face with the full uv square (assets.cpp:1474-1570). The reference builds
+    these vertices without a colour (value-initialised to 0; no shader reads it)."""
     faces = [  # (uv origin, uv x edge, uv y edge, normal)
         ((-1, -1, 1), (2, 0, 0), (0, 0, -2), (0, -1, 0)),
         ((-1, 1, -1), (2, 0, 0), (0, 0, 2), (0, 1, 0)),
@@ -77,7 +78,7 @@ def cube_mesh():
         base = len(rows)
         rows += [(o, (0, 0), normal), (o + ex, (1, 0), normal), (o + ex + ey, (1, 1), normal), (o + ey, (0, 1), normal)]
         indices += [base, base + 1, base + 2, base, base + 2, base + 3]
-    return _vertices(rows), np.array(indices, np.uint32)
+    return _vertices(rows, color=(0.0, 0.0, 0.0, 0.0)), np.array(indices, np.uint32)
 
 
 def transform_matrix(translation=(0, 0, 0), eulers=(0, 0, 0), scale=(1, 1, 1)):

@@ -5,6 +5,7 @@
 #include <cstring>
 #include <vector>
 
+#include "szg/assets.hpp"
 #include "szg/pipelines.hpp"
 
 namespace
@@ -118,11 +119,12 @@ int main(int argc, char** argv)
 {
     if (argc < 4)
     {
-        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes]\n");
+        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes | gltf <file> [loader flags]]\n");
         return 2;
     }
     uint32_t const W = (uint32_t)std::atoi(argv[2]), H = (uint32_t)std::atoi(argv[3]);
-    bool const realMeshes = argc > 4 && std::strcmp(argv[4], "meshes") == 0;
+    bool const gltf = argc > 5 && std::strcmp(argv[4], "gltf") == 0;
+    bool const realMeshes = gltf || (argc > 4 && std::strcmp(argv[4], "meshes") == 0);
 
     // scene -> packed blocks (renderer.cpp:302-342)
     szg_camera camera;
@@ -177,7 +179,57 @@ int main(int argc, char** argv)
 
     // renderer.cpp:383-415
     DefaultScene scene;
-    if (realMeshes)
+    if (gltf)
+    {
+        // An engine-style caller: asset library -> mesh instances -> recordDrawCommands (editor.cpp:500-545 does this with
+        // the library's cube and plane). Every mesh of the file gets two instances; the floor is the built-in plane.
+        auto library = szg::AssetLibrary::loadDefaultAssets();
+        if (!library.has_value())
+        {
+            std::fprintf(stderr, "default assets failed: %s\n", szg_last_error());
+            return 1;
+        }
+        size_t const builtins = library->meshes().size();
+        if (library->loadGLTFFromPath(argv[5], argc > 6 ? (uint32_t)std::atoi(argv[6]) : 0u) == 0)
+        {
+            std::fprintf(stderr, "no mesh loaded\n");
+            return 1;
+        }
+        std::vector<szg::MeshInstanced> instances(library->meshes().size() - builtins + 1);
+        for (size_t k = 0; k + 1 < instances.size(); k++)
+        {
+            float const fk = (float)k;
+            szg_transform const two[2] = {{{-3.0f + 8.0f * fk, -6.0f, 2.0f}, {0.3f, 0.2f, 0.1f}, {4.0f, 4.0f, 4.0f}},
+                                          {{6.0f, -4.0f, 8.0f + 4.0f * fk}, {0.0f, 1.0f, 0.0f}, {3.0f, 5.0f, 3.0f}}};
+            instances[k].setMesh(library->meshes()[builtins + k]);
+            instances[k].setInstances(two);
+            instances[k].render = true;
+            instances[k].name = library->meshes()[builtins + k]->name;
+        }
+        szg_transform const floor[1] = {{{0.0f, -1.0f, 0.0f}, {0.0f, 0.0f, 0.0f}, {20.0f, 1.0f, 20.0f}}};
+        instances.back().setMesh(library->defaultMesh(szg::AssetLibrary::DefaultMeshAssets::Plane));
+        instances.back().setInstances(floor);
+        instances.back().render = true;
+        std::vector<szg_mesh_instanced> views;
+        for (szg::MeshInstanced& instance : instances)
+        {
+            instance.prepareForRendering(cmd);
+            views.push_back(instance.view());
+        }
+        deferred.recordDrawCommands(cmd, sceneSubregion, *sceneTexture, 1, lights, spotlights, 0, cameras, std::span<szg_mesh_instanced const>{views});
+        skyView->recordDrawCommands(cmd, *sceneTexture, sceneSubregion, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0,
+                                    cameras, 0, lights);
+        if (hipStreamSynchronize(cmd) != hipSuccess) // before the instances and the library (their device memory) go away
+        {
+            std::fprintf(stderr, "stream failed\n");
+            return 1;
+        }
+        for (auto const& mesh : library->meshes())
+        {
+            std::printf("%s %u vertices %zu surfaces\n", mesh->name.c_str(), mesh->meshBuffers->vertexCount, mesh->surfaces.size());
+        }
+    }
+    else if (realMeshes)
     {
         if (!scene.build())
         {
@@ -192,8 +244,11 @@ int main(int argc, char** argv)
     {
         deferred.recordDrawCommands(cmd, sceneSubregion, *sceneTexture, 1, lights, spotlights, 0, cameras, &geometry);
     }
-    skyView->recordDrawCommands(cmd, *sceneTexture, sceneSubregion, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0,
-                                cameras, 0, lights);
+    if (!gltf)
+    {
+        skyView->recordDrawCommands(cmd, *sceneTexture, sceneSubregion, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0,
+                                    cameras, 0, lights);
+    }
     if (hipStreamSynchronize(cmd) != hipSuccess)
     {
         std::fprintf(stderr, "stream failed\n");

@@ -499,6 +499,18 @@ def test_default_material_maps_are_the_asset_library_defaults():
         assets.default_material_map(3)
 
 
+def test_default_meshes_are_the_asset_library_builtins():
+    # assets.cpp:1400-1610, regenerated independently in syzygy_amd/meshes.py: byte for byte the same vertex records
+    for kind, (vertices, indices), name, half in [(abi.SZG_DEFAULT_MESH_CUBE, meshes.cube_mesh(), "mesh_Cube", (1, 1, 1)),
+                                                  (abi.SZG_DEFAULT_MESH_PLANE, meshes.plane_mesh(), "mesh_Plane", (1, 0, 1))]:
+        m = assets.default_mesh(kind)
+        assert m.name == name and m.vertices.tobytes() == vertices.tobytes() and (m.indices == indices).all()
+        assert m.surfaces == [(0, len(indices), -1)]
+        assert (m.bounds[0] == 0).all() and (m.bounds[1] == np.array(half, np.float32)).all()
+    with pytest.raises(assets.AssetError):
+        assets.default_mesh(2)
+
+
 def test_sphere_asset_is_outward_facing_after_the_flip():
     """The reference's shipped asset is a sphere (assets/sphere.glb, an LFS pointer here): an equivalent one is written,
     loaded, and must come out clockwise-front in engine space (+y down) as the raster state expects (deferred.cpp:380)."""

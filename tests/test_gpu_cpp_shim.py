@@ -95,3 +95,74 @@ def test_cpp_record_draw_with_real_meshes_matches_oracle(tmp_path):
     ob.composite(frame, rect, None, host_maps, atm, cam, dirs, 0, tl, sl, threads=8)
     assert (frame.depth > 0).mean() > 0.1
     assert np.abs(got.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+
+
+def test_cpp_asset_library_gltf_to_frame_matches_oracle(tmp_path):
+    """An engine-style C++ caller end to end (include/szg/assets.hpp): AssetLibrary::loadDefaultAssets + loadGLTFFromPath on a
+    GLB written to disk, MeshInstanced with two transforms per loaded mesh and the built-in plane as the floor,
+    recordDrawCommands + the sky-view pipeline — against the oracle chain fed by the Python mirror of the same loader."""
+    import ctypes as C
+
+    from oracle import binding as ob
+    from syzygy_amd import abi, assets, lib, meshes, scene
+    from tests import gltf_writer as gw
+
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpp"), "record_draw"], check=True)
+    exe = os.path.join(HERE, "cpp", "record_draw")
+    rng = np.random.default_rng(5)
+    pos, nrm, uv, idx = gw.uv_sphere(10, 20)
+    b = gw.GltfBuilder()
+    y, x = np.mgrid[0:16, 0:32]
+    color = np.stack([(x * 8) & 255, (y * 16) & 255, ((x ^ y) * 16) & 255, np.full_like(x, 255)], -1).astype(np.uint8)
+    t_color = b.texture(b.image_uri(gw.data_uri_png(gw.png_rgba8(color))))
+    t_mr = b.texture(b.image_view(gw.png_rgba8(rng.integers(0, 256, (4, 4, 4), dtype=np.uint8))))
+    b.doc["materials"] = [{"name": "painted", "pbrMetallicRoughness": {"baseColorTexture": {"index": t_color},
+                                                                       "metallicRoughnessTexture": {"index": t_mr}}}]
+    attrs = {"POSITION": b.accessor(pos), "NORMAL": b.accessor(nrm), "TEXCOORD_0": b.accessor(uv)}
+    b.doc["meshes"] = [{"name": "Sphere", "primitives": [{"attributes": attrs, "indices": b.accessor(idx.astype(np.uint16)), "material": 0}]},
+                       {"name": "Sphere", "primitives": [{"attributes": attrs, "indices": b.accessor(idx[: len(idx) // 2])}]}]
+    path = tmp_path / "two spheres.glb"
+    path.write_bytes(b.glb())
+
+    W, H, DIM = 200, 120, 512
+    out = tmp_path / "frame_gltf.bin"
+    flags = abi.SZG_GLTF_DECODE_BUFFER_VIEW_IMAGES
+    r = subprocess.run([exe, str(out), str(W), str(H), "gltf", str(path), str(flags)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    # names are deduplicated like the reference's (assets.cpp:1678-1692)
+    assert "mesh_Plane 4 vertices 1 surfaces" in r.stdout and "mesh_Cube 24 vertices" in r.stdout
+    assert "mesh_Sphere 231 vertices 1 surfaces" in r.stdout and "mesh_Sphere_2 231 vertices" in r.stdout
+    got = np.fromfile(out, dtype=np.uint16).reshape(H, W, 4)
+
+    a = assets.load_gltf(str(path), flags)
+    ms = []
+    for k in range(2):
+        models = [meshes.transform_matrix((-3.0 + 8.0 * k, -6.0, 2.0), (0.3, 0.2, 0.1), (4, 4, 4)),
+                  meshes.transform_matrix((6.0, -4.0, 8.0 + 4.0 * k), (0.0, 1.0, 0.0), (3, 5, 3))]
+        ms.append(a.instanced(k, models))
+    ms.append(meshes.reference_default_scene()[2])
+
+    cam = scene.camera_packed(scene.default_camera(), np.float32(W) / np.float32(H))
+    atmosphere = scene.default_atmosphere()
+    atmosphere.sunEulerAngles[0] = np.float32(np.float32(3.14159265358979) + np.float32(35.0) * np.float32(3.14159265358979) / np.float32(180.0))
+    atm, sun, moon = scene.atmosphere_baked(atmosphere, scene.aabb((0.0, -7.0, 39.0), (64.0, 8.0, 46.0)))
+    spot = scene.make_spot((1, 0, 0), (-20.0, -28.0, -20.0), scene.eulers_from_forward((20.0, 20.0, 20.0)))
+    spots = (abi.SpotLightPacked * 1)(spot)
+    maps = []
+    for light in (sun, moon, spot):
+        pv = abi.Mat4()
+        lib().szg_mat4_mul(C.byref(light.projection), C.byref(light.view), C.byref(pv))
+        maps.append(ob.shadow_raster(pv, DIM, ms, threads=8))
+    images = (abi.Image * len(maps))(*[ob.host_image(m, abi.SZG_FORMAT_D32_SFLOAT) for m in maps])
+    host_maps = abi.ShadowMaps(len(maps), 0, C.cast(images, C.POINTER(abi.Image)))
+    rect = abi.Rect(0, 0, W, H)
+    frame = ob.HostFrame(W, H)
+    dirs = (abi.DirectionalLightPacked * 2)(sun, moon)
+    ob.gbuffer_raster(frame, rect, None, cam, ms, threads=8)
+    ob.lights(frame, rect, None, host_maps, cam, dirs, 2, 1, spots, 1, threads=8)
+    tl = ob.transmittance_lut(atm, 512, 128, threads=8)
+    sl = ob.skyview_lut(atm, cam, tl, 2048, 1024, threads=16)
+    ob.composite(frame, rect, None, host_maps, atm, cam, dirs, 0, tl, sl, threads=8)
+    sphere = (frame.planes()["occlusionRoughnessMetallic"][..., 1] != np.float16(60 / 255)) & (frame.depth > 0)
+    assert sphere.mean() > 0.03
+    assert np.abs(got.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
