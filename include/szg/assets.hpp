@@ -14,7 +14,7 @@
 //   MeshInstanced       renderer/scene.hpp:109-147              szg::MeshInstanced: originals / transforms, models +
 //                                                               modelInverseTransposes staged buffers, setMesh,
 //                                                               material overrides
-//   Scene::tick + prepareForRendering  scene.cpp:461-523, :197-215   MeshInstanced::tick / prepareForRendering
+//   tickMeshInstance    renderer/scene.cpp:461-523              MeshInstanced::tick (+ recordCopyToDevice, renderer.cpp:344-353)
 //
 // Error behaviour follows the reference: a failed load logs and leaves the library unchanged; nothing throws.
 #pragma once
@@ -315,16 +315,25 @@ struct MeshInstanced
 
     std::vector<szg_transform> originals{};
     std::vector<szg_transform> transforms{};
-    TStagedBuffer<szg_mat4> models{};
-    TStagedBuffer<szg_mat4> modelInverseTransposes{};
+    std::unique_ptr<TStagedBuffer<szg_mat4>> models{};
+    std::unique_ptr<TStagedBuffer<szg_mat4>> modelInverseTransposes{};
 
-    // Scene::addMeshInstance-style setup (scene.cpp:230-290): capacity for the instances, originals = transforms
+    // The instance part of Scene::addMeshInstance (scene.cpp:181-213): originals = transforms = the given ones, both staged
+    // buffers sized for them and filled with Transform::toMatrix() and its inverse transpose.
     void setInstances(std::span<szg_transform const> instances)
     {
         originals.assign(instances.begin(), instances.end());
         transforms = originals;
-        models = TStagedBuffer<szg_mat4>::allocate(instances.size());
-        modelInverseTransposes = TStagedBuffer<szg_mat4>::allocate(instances.size());
+        models = std::make_unique<TStagedBuffer<szg_mat4>>(TStagedBuffer<szg_mat4>::allocate(instances.size()));
+        modelInverseTransposes = std::make_unique<TStagedBuffer<szg_mat4>>(TStagedBuffer<szg_mat4>::allocate(instances.size()));
+        for (szg_transform const& t : originals)
+        {
+            szg_mat4 model{}, inverseTranspose{};
+            szg_transform_matrix(t.translation, t.eulerAnglesRadians, t.scale, &model);
+            szg_mat4_inverse_transpose(&model, &inverseTranspose);
+            models->push(model);
+            modelInverseTransposes->push(inverseTranspose);
+        }
     }
     void setMesh(std::shared_ptr<Mesh const> mesh)
     {
@@ -344,26 +353,44 @@ struct MeshInstanced
         m_view.clear();
     }
 
-    // Scene::tick for this instance group (scene.cpp:461-523) and Scene::prepareForRendering (scene.cpp:197-215): the model
-    // matrices and their inverse transposes are recomputed, staged and copied on `cmd`.
-    void prepareForRendering(hipStream_t cmd, double elapsedSeconds = 0.0, double deltaSeconds = 0.0)
+    // tickMeshInstance (scene.cpp:461-523): the animation advances `transforms`; the staged matrices are rebuilt
+    void tick(double elapsedSeconds, double deltaSeconds)
     {
+        if (models == nullptr || modelInverseTransposes == nullptr)
+        {
+            return;
+        }
         std::vector<szg_mat4> m(transforms.size()), mit(transforms.size());
         szg_tick_mesh_instance(animation, originals.data(), transforms.data(), static_cast<uint32_t>(transforms.size()), elapsedSeconds,
                                deltaSeconds, m.data(), mit.data());
-        models.clearStaged();
-        models.push(m);
-        models.recordCopyToDevice(cmd);
-        modelInverseTransposes.clearStaged();
-        modelInverseTransposes.push(mit);
-        modelInverseTransposes.recordCopyToDevice(cmd);
+        models->clearStaged();
+        models->push(m);
+        modelInverseTransposes->clearStaged();
+        modelInverseTransposes->push(mit);
+    }
+    // renderer.cpp:344-353
+    void recordCopyToDevice(hipStream_t cmd) const
+    {
+        if (models != nullptr)
+        {
+            models->recordCopyToDevice(cmd);
+        }
+        if (modelInverseTransposes != nullptr)
+        {
+            modelInverseTransposes->recordCopyToDevice(cmd);
+        }
+    }
+    void prepareForRendering(hipStream_t cmd, double elapsedSeconds = 0.0, double deltaSeconds = 0.0)
+    {
+        tick(elapsedSeconds, deltaSeconds);
+        recordCopyToDevice(cmd);
     }
 
     // The record szg/raster.h consumes; valid while this object and its mesh live and until the next override.
     [[nodiscard]] auto view() const -> szg_mesh_instanced
     {
         szg_mesh_instanced out{};
-        if (m_mesh == nullptr || m_mesh->meshBuffers == nullptr)
+        if (m_mesh == nullptr || m_mesh->meshBuffers == nullptr || models == nullptr || modelInverseTransposes == nullptr)
         {
             return out;
         }
@@ -396,9 +423,9 @@ struct MeshInstanced
         out.index_count = m_mesh->meshBuffers->indexCount;
         out.surfaces = m_view.data();
         out.surface_count = static_cast<uint32_t>(m_view.size());
-        out.d_models = reinterpret_cast<szg_mat4 const*>(models.deviceAddress());
-        out.d_model_inverse_transposes = reinterpret_cast<szg_mat4 const*>(modelInverseTransposes.deviceAddress());
-        out.instance_count = static_cast<uint32_t>(models.deviceSize());
+        out.d_models = models->deviceAddress();
+        out.d_model_inverse_transposes = modelInverseTransposes->deviceAddress();
+        out.instance_count = static_cast<uint32_t>(models->deviceSize());
         out.render = render ? 1u : 0u;
         out.casts_shadow = castsShadow ? 1u : 0u;
         return out;

@@ -124,6 +124,10 @@ typedef struct szg_shadow_caster
 } szg_shadow_caster;
 /* geometrytypes.cpp:11-19 AABB::create */
 void szg_aabb_create(const float min[3], const float max[3], szg_aabb* out);
+/* Transform::lookAt(Ray::create(from, to), scale) (geometry/transform.cpp:17-28): translation = from, eulers =
+ * eulersFromForward(normalize(to - from)). */
+void szg_transform_look_at(const float from[3], const float to[3], const float scale[3], szg_transform* out);
+
 /* Scene::calculateShadowBounds (scene.cpp:95-148): the world AABB of every rendered shadow caster's transformed
  * vertex-bounds corners; the `captured_bounds` of szg_atmosphere_baked / szg_make_directional. Returns 0 and leaves
  * *out zeroed when no caster contributes (scene.cpp:138-143), 1 otherwise. */

@@ -462,6 +462,7 @@ HOST_FUNCTIONS = {
     "szg_view_vk": (None, [P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_transform_matrix": (None, [P(C.c_float), P(C.c_float), P(C.c_float), P(Mat4)]),
     "szg_aabb_create": (None, [P(C.c_float), P(C.c_float), P(AABB)]),
+    "szg_transform_look_at": (None, [P(C.c_float), P(C.c_float), P(C.c_float), P(Transform)]),
     "szg_calculate_shadow_bounds": (C.c_int, [P(ShadowCaster), U32, P(AABB)]),
     "szg_tick_mesh_instance": (None, [U32, P(Transform), P(Transform), U32, C.c_double, C.c_double, P(Mat4), P(Mat4)]),
     "szg_projection_ortho_aabb_vk": (None, [P(Mat4), P(AABB), P(Mat4)]),

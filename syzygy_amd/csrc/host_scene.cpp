@@ -351,6 +351,14 @@ void szg_transform_matrix(const float translation[3], const float eulers[3], con
     at(sc, 3, 3) = 1.0f;
     *out = mul(mul(translate(v3(translation)), orientate4(v3(eulers))), sc);
 }
+// geometry/transform.cpp:17-28 Transform::lookAt over Ray::create(from, to) (direction = to - from, possibly unnormalised)
+void szg_transform_look_at(const float from[3], const float to[3], const float scale[3], szg_transform* out)
+{
+    V3 const forward = normalize(v3(to) - v3(from));
+    store(out->translation, v3(from));
+    store(out->eulerAnglesRadians, eulersFromForward(forward));
+    store(out->scale, v3(scale));
+}
 void szg_projection_ortho_aabb_vk(const szg_mat4* view, const szg_aabb* bounds, szg_mat4* out)
 {
     *out = projectionOrthoAABBVk(*view, *bounds);

@@ -7,6 +7,7 @@
 
 #include "szg/assets.hpp"
 #include "szg/pipelines.hpp"
+#include "szg/scene.hpp"
 
 namespace
 {
@@ -115,14 +116,64 @@ struct DefaultScene
 };
 } // namespace
 
+// The engine's own frame, written the way Editor::run + Renderer::recordDraw write it (editor.cpp:500-545, renderer.cpp:278-443):
+// asset library -> Scene::defaultScene -> ticks -> shadow bounds -> Renderer::recordDraw. Everything here is the
+// header-only mirrors of include/szg/{assets,scene,pipelines}.hpp.
+int engineFrame(const char* outPath, uint32_t W, uint32_t H, int ticks)
+{
+    auto library = szg::AssetLibrary::loadDefaultAssets();
+    auto renderer = szg::Renderer::create(W, H, 512);
+    auto sceneTexture = szg::SceneTexture::create(W, H);
+    if (!library.has_value() || !renderer.has_value() || !sceneTexture)
+    {
+        std::fprintf(stderr, "setup failed: %s\n", szg_last_error());
+        return 1;
+    }
+    szg::Scene scene = szg::Scene::defaultScene(library->defaultMesh(szg::AssetLibrary::DefaultMeshAssets::Cube));
+    scene.sunAnimation.time = 0.6f; // afternoon
+    scene.geometry()[1].animation = SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP;
+    hipStream_t cmd = nullptr;
+    (void)hipStreamCreate(&cmd);
+    szg_rect const sceneSubregion{0, 0, W, H};
+    double elapsed = 0.0;
+    for (int k = 0; k < ticks; k++)
+    {
+        double const dt = 1.0 / 60.0;
+        scene.tick(szg::TickTiming{elapsed, dt});
+        elapsed += dt;
+        scene.calculateShadowBounds();
+        renderer->recordDraw(cmd, scene, *sceneTexture, sceneSubregion);
+    }
+    if (hipStreamSynchronize(cmd) != hipSuccess)
+    {
+        std::fprintf(stderr, "stream failed\n");
+        return 1;
+    }
+    std::vector<uint16_t> host((size_t)W * H * 4);
+    (void)hipMemcpy2D(host.data(), (size_t)W * 8, sceneTexture->color().data, sceneTexture->color().pitch_bytes, (size_t)W * 8, H,
+                      hipMemcpyDeviceToHost);
+    FILE* f = std::fopen(outPath, "wb");
+    std::fwrite(host.data(), 2, host.size(), f);
+    std::fclose(f);
+    szg_aabb const b = scene.shadowBounds();
+    std::printf("ok %ux%u sun %.9g bounds %.9g %.9g %.9g / %.9g %.9g %.9g\n", W, H, scene.atmosphere.sunEulerAngles[0], b.center[0], b.center[1],
+                b.center[2], b.half_extent[0], b.half_extent[1], b.half_extent[2]);
+    (void)hipStreamDestroy(cmd);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 4)
     {
-        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes | gltf <file> [loader flags]]\n");
+        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes | gltf <file> [loader flags] | scene [ticks]]\n");
         return 2;
     }
     uint32_t const W = (uint32_t)std::atoi(argv[2]), H = (uint32_t)std::atoi(argv[3]);
+    if (argc > 4 && std::strcmp(argv[4], "scene") == 0)
+    {
+        return engineFrame(argv[1], W, H, argc > 5 ? std::atoi(argv[5]) : 3);
+    }
     bool const gltf = argc > 5 && std::strcmp(argv[4], "gltf") == 0;
     bool const realMeshes = gltf || (argc > 4 && std::strcmp(argv[4], "meshes") == 0);
 

@@ -166,3 +166,88 @@ def test_cpp_asset_library_gltf_to_frame_matches_oracle(tmp_path):
     sphere = (frame.planes()["occlusionRoughnessMetallic"][..., 1] != np.float16(60 / 255)) & (frame.depth > 0)
     assert sphere.mean() > 0.03
     assert np.abs(got.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+
+
+def test_cpp_engine_frame_scene_and_renderer_match_oracle(tmp_path):
+    """The engine's own frame in C++ (include/szg/scene.hpp): AssetLibrary::loadDefaultAssets -> Scene::defaultScene (floor that
+    casts no shadow, floating cube, two look-at spot lights of strength 30) -> three ticks (sun animation, spinning cube) ->
+    calculateShadowBounds -> Renderer::recordDraw. The same scene is rebuilt here from the C-ABI pieces and rendered by the
+    oracle chain."""
+    import ctypes as C
+
+    from oracle import binding as ob
+    from syzygy_amd import abi, assets, lib, meshes, scene
+
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpp"), "record_draw"], check=True)
+    exe = os.path.join(HERE, "cpp", "record_draw")
+    W, H, DIM, TICKS = 200, 120, 512, 3
+    out = tmp_path / "frame_scene.bin"
+    r = subprocess.run([exe, str(out), str(W), str(H), "scene", str(TICKS)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = np.fromfile(out, dtype=np.uint16).reshape(H, W, 4)
+    reported = [float(v) for v in r.stdout.split() if v.replace(".", "").replace("-", "").replace("e", "").replace("+", "").isdigit()]
+
+    L = lib()
+    cube = assets.default_mesh(abi.SZG_DEFAULT_MESH_CUBE)
+    material = meshes.default_material()
+
+    def transform(t, s):
+        out_t = abi.Transform()
+        out_t.translation[:], out_t.eulerAnglesRadians[:], out_t.scale[:] = list(t), [0.0, 0.0, 0.0], list(s)
+        return out_t
+
+    groups = [  # (transform, animation, casts shadow)  scene.cpp:238-279
+        (transform((0.0, 0.0, 0.0), (400.0, 1.0, 400.0)), abi.SZG_INSTANCE_ANIMATION_NONE, False),
+        (transform((0.0, -4.0, 0.0), (1.0, 1.0, 1.0)), abi.SZG_INSTANCE_ANIMATION_SPIN_ALONG_WORLD_UP, True),
+    ]
+    atmosphere = scene.default_atmosphere()
+    anim = abi.SunAnimation()
+    L.szg_sun_animation_default(C.byref(anim))
+    anim.time = 0.6
+    state = [((abi.Transform * 1)(g[0]), (abi.Transform * 1)(g[0]), (abi.Mat4 * 1)(), (abi.Mat4 * 1)()) for g in groups]
+    elapsed, dt = 0.0, 1.0 / 60.0
+    for _ in range(TICKS):
+        L.szg_scene_tick_sun(C.byref(anim), C.byref(atmosphere), dt)
+        for (t0, animation, _), (orig, cur, models, mits) in zip(groups, state):
+            L.szg_tick_mesh_instance(animation, orig, cur, 1, elapsed, dt, models, mits)
+        elapsed += dt
+    bounds_of_cube = abi.AABB()
+    bounds_of_cube.center[:], bounds_of_cube.half_extent[:] = [float(v) for v in cube.bounds[0]], [float(v) for v in cube.bounds[1]]
+    casters = (abi.ShadowCaster * 2)(*[abi.ShadowCaster(bounds_of_cube, st[1], 1, 1, int(g[2]), 0) for g, st in zip(groups, state)])
+    bounds = abi.AABB()
+    L.szg_calculate_shadow_bounds(casters, 2, C.byref(bounds))
+    # the C++ side reports its sun angle and shadow bounds: the host layers agree before any pixel is compared
+    assert np.allclose(reported[-7:], [atmosphere.sunEulerAngles[0]] + list(bounds.center) + list(bounds.half_extent), rtol=1e-6, atol=1e-6)
+
+    ms = [meshes.MeshInstanced(cube.vertices, cube.indices, [(0, len(cube.indices), material)], [st[2][0]], casts_shadow=g[2])
+          for g, st in zip(groups, state)]
+    spots = (abi.SpotLightPacked * 2)()
+    for k, (sign, color) in enumerate([(1.0, (0.0, 1.0, 0.0, 1.0)), (-1.0, (1.0, 0.0, 0.0, 1.0))]):  # scene.cpp:281-331
+        look = abi.Transform()
+        L.szg_transform_look_at(abi.f3(sign * 8.0, -12.0, sign * 8.0), abi.f3(0.0, -4.0, 0.0), abi.f3(1.0, 1.0, 1.0), C.byref(look))
+        p = abi.SpotlightParams()
+        p.color[:] = list(color)
+        p.strength, p.falloffFactor, p.falloffDistance, p.verticalFOVDegrees, p.horizontalScale = 30.0, 1.0, 1.0, 60.0, 1.0
+        p.eulerAngles[:], p.position[:] = list(look.eulerAnglesRadians), list(look.translation)
+        p.near_plane, p.far_plane = 0.1, 1000.0
+        L.szg_make_spot(C.byref(p), C.byref(spots[k]))
+
+    cam = scene.camera_packed(scene.default_camera(), np.float32(np.float64(W) / np.float64(H)))
+    atm, sun, moon = scene.atmosphere_baked(atmosphere, bounds)
+    maps = []
+    for light in (sun, moon, spots[0], spots[1]):
+        pv = abi.Mat4()
+        L.szg_mat4_mul(C.byref(light.projection), C.byref(light.view), C.byref(pv))
+        maps.append(ob.shadow_raster(pv, DIM, ms, threads=8))
+    images = (abi.Image * len(maps))(*[ob.host_image(m, abi.SZG_FORMAT_D32_SFLOAT) for m in maps])
+    host_maps = abi.ShadowMaps(len(maps), 0, C.cast(images, C.POINTER(abi.Image)))
+    rect = abi.Rect(0, 0, W, H)
+    frame = ob.HostFrame(W, H)
+    dirs = (abi.DirectionalLightPacked * 2)(sun, moon)
+    ob.gbuffer_raster(frame, rect, None, cam, ms, threads=8)
+    ob.lights(frame, rect, None, host_maps, cam, dirs, 2, 1, spots, 2, threads=8)
+    tl = ob.transmittance_lut(atm, 512, 128, threads=8)
+    sl = ob.skyview_lut(atm, cam, tl, 2048, 1024, threads=16)
+    ob.composite(frame, rect, None, host_maps, atm, cam, dirs, 0, tl, sl, threads=8)
+    assert (frame.depth > 0).mean() > 0.3
+    assert np.abs(got.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1

@@ -328,3 +328,27 @@ def test_calculate_shadow_bounds_of_the_default_scene():
         c.render = 0
     assert lib().szg_calculate_shadow_bounds(casters, 3, C.byref(out)) == 0
     assert list(out.center) == [0.0, 0.0, 0.0] and list(out.half_extent) == [0.0, 0.0, 0.0]
+
+
+def test_transform_look_at_is_eulers_from_the_normalised_direction():
+    """Transform::lookAt(Ray::create(from, to), scale) (geometry/transform.cpp:17-28)."""
+    import ctypes as C
+
+    from syzygy_amd import abi, lib
+
+    rng = np.random.default_rng(12)
+    for _ in range(50):
+        a, b = rng.normal(0, 10, 3).astype(np.float32), rng.normal(0, 10, 3).astype(np.float32)
+        scale = rng.uniform(0.5, 2.0, 3).astype(np.float32)
+        t = abi.Transform()
+        lib().szg_transform_look_at(abi.f3(*a), abi.f3(*b), abi.f3(*scale), C.byref(t))
+        assert (np.array(t.translation, np.float32) == a).all() and (np.array(t.scale, np.float32) == scale).all()
+        d = (b - a).astype(np.float32)
+        forward = d * (np.float32(1.0) / np.sqrt(np.dot(d, d).astype(np.float32)))
+        want = (C.c_float * 3)()
+        lib().szg_eulers_from_forward(abi.f3(*forward), want)
+        assert np.allclose(np.array(t.eulerAnglesRadians), np.array(want), rtol=0, atol=2e-7)
+        # and the forward vector of those eulers is the direction again
+        back = (C.c_float * 3)()
+        lib().szg_forward_from_eulers(t.eulerAnglesRadians, back)
+        assert np.allclose(np.array(back), d / np.linalg.norm(d), atol=2e-6)
