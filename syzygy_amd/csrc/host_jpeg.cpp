@@ -1,4 +1,4 @@
-// host_jpeg.cpp — baseline / extended-sequential Huffman JPEG -> RGBA8 for szg/assets.h, the second image encoding
+// host_jpeg.cpp — baseline / extended-sequential / progressive Huffman JPEG -> RGBA8 for szg/assets.h, the second image encoding
 // glTF 2.0 allows. The reference decodes through stb_image (assets.cpp:319-364, stbi_load_from_memory(..., 4)), which is
 // not under /root/reference; JPEG leaves the inverse DCT, the chroma upsampling filter and the colour conversion to the
 // decoder, so stb_image's published integer arithmetic is what is restated here:
@@ -7,7 +7,9 @@
 //   YCbCr -> RGB       20-bit fixed point, the Cb term of green masked to its high 16 bits
 // Parity unpinned (no stb_image, no JPEG asset in the checkout): tests/test_assets.py checks against an independent numpy
 // restatement of the same arithmetic and against the source picture within JPEG's own error.
-// Not decoded: progressive (SOF2), arithmetic coding, 12-bit, CMYK / YCCK — such files fail like any undecodable image.
+// Progressive files (SOF2: spectral selection and successive approximation, T.81 annex G) accumulate their coefficients
+// over the scans and are dequantised and transformed at the end, as stb_image does.
+// Not decoded: arithmetic coding, lossless / hierarchical, 12-bit, CMYK / YCCK — such files fail like any undecodable image.
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -81,6 +83,8 @@ struct Component
     int w2 = 0, h2 = 0; // allocated size: whole MCUs
     int prediction = 0;
     std::vector<uint8_t> data;
+    std::vector<int16_t> coefficients; // progressive only: 64 per block, blocks in rows of coefficientWidth
+    int coefficientWidth = 0, coefficientHeight = 0;
 };
 
 class Decoder
@@ -109,8 +113,9 @@ class Decoder
             {
                 break;
             }
-            if (marker == 0xC0 || marker == 0xC1)
+            if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2)
             {
+                progressive_ = marker == 0xC2;
                 if (haveFrame || !frameHeader(why))
                 {
                     if (why.empty())
@@ -120,11 +125,6 @@ class Decoder
                     return false;
                 }
                 haveFrame = true;
-            }
-            else if (marker == 0xC2)
-            {
-                why = "progressive JPEG is not decoded by this build";
-                return false;
             }
             else if ((marker >= 0xC3 && marker <= 0xCF && marker != 0xC4 && marker != 0xC8 && marker != 0xCC) || marker == 0xC8)
             {
@@ -215,6 +215,10 @@ class Decoder
         why.clear();
         width = static_cast<uint32_t>(width_);
         height = static_cast<uint32_t>(height_);
+        if (progressive_)
+        {
+            finishProgressive();
+        }
         output(rgba);
         return true;
     }
@@ -230,6 +234,8 @@ class Decoder
     Huffman dc_[4], ac_[4];
     int restartInterval_ = 0;
     bool jfif_ = false;
+    bool progressive_ = false;
+    int eobRun_ = 0;
     int adobeTransform_ = -1;
     int rgbIds_ = 0;
 
@@ -418,6 +424,12 @@ class Decoder
             c.w2 = mcuX_ * c.h * 8;
             c.h2 = mcuY_ * c.v * 8;
             c.data.assign(static_cast<size_t>(c.w2) * static_cast<size_t>(c.h2), 0);
+            if (progressive_)
+            {
+                c.coefficientWidth = c.w2 / 8;
+                c.coefficientHeight = c.h2 / 8;
+                c.coefficients.assign(static_cast<size_t>(c.w2) * static_cast<size_t>(c.h2), 0);
+            }
         }
         return true;
     }
@@ -506,9 +518,188 @@ class Decoder
     {
         bitBuffer_ = 0;
         bitCount_ = 0;
+        eobRun_ = 0;
         for (Component& c : components_)
         {
             c.prediction = 0;
+        }
+    }
+    int getBit() { return receiveBits(1); }
+    int receiveBits(int n)
+    {
+        if (n == 0)
+        {
+            return 0;
+        }
+        if (bitCount_ < n)
+        {
+            fill();
+        }
+        int const value = static_cast<int>(bitBuffer_ >> (32 - n));
+        bitBuffer_ <<= n;
+        bitCount_ -= n;
+        return value;
+    }
+
+    // T.81 G.1.2: one block of a progressive scan. DC scans (specStart == 0) code the prediction difference shifted by
+    // the point transform, or one refinement bit; AC scans code bands of coefficients with end-of-band runs, first pass or
+    // refinement (correction bits for coefficients that are already non-zero, newly non-zero ones of magnitude 1 << low).
+    bool decodeProgressiveDc(Component& c, int16_t* data, int high, int low)
+    {
+        if (high == 0)
+        {
+            int const t = decodeSymbol(dc_[c.td]);
+            if (t < 0 || t > 15)
+            {
+                return false;
+            }
+            c.prediction = static_cast<int>(static_cast<unsigned>(c.prediction) + static_cast<unsigned>(receiveExtend(t)));
+            data[0] = static_cast<int16_t>(static_cast<unsigned>(c.prediction) * (1u << low));
+        }
+        else if (getBit() != 0)
+        {
+            data[0] = static_cast<int16_t>(data[0] + static_cast<int16_t>(1 << low));
+        }
+        return true;
+    }
+    bool decodeProgressiveAc(Component& c, int16_t* data, int specStart, int specEnd, int high, int low)
+    {
+        const Huffman& table = ac_[c.ta];
+        if (high == 0)
+        {
+            if (eobRun_ != 0)
+            {
+                eobRun_--;
+                return true;
+            }
+            int k = specStart;
+            do
+            {
+                int const rs = decodeSymbol(table);
+                if (rs < 0)
+                {
+                    return false;
+                }
+                int const size = rs & 15, run = rs >> 4;
+                if (size == 0)
+                {
+                    if (run < 15)
+                    {
+                        eobRun_ = (1 << run);
+                        if (run != 0)
+                        {
+                            eobRun_ += receiveBits(run);
+                        }
+                        eobRun_--;
+                        break;
+                    }
+                    k += 16;
+                }
+                else
+                {
+                    k += run;
+                    if (k > 63)
+                    {
+                        return false;
+                    }
+                    data[DEZIGZAG[k++]] = static_cast<int16_t>(static_cast<unsigned>(receiveExtend(size)) * (1u << low));
+                }
+            } while (k <= specEnd);
+            return true;
+        }
+        int16_t const bit = static_cast<int16_t>(1 << low);
+        auto correct = [&](int16_t& p) {
+            if (getBit() != 0 && (p & bit) == 0)
+            {
+                p = static_cast<int16_t>(p > 0 ? p + bit : p - bit);
+            }
+        };
+        if (eobRun_ != 0)
+        {
+            eobRun_--;
+            for (int k = specStart; k <= specEnd; k++)
+            {
+                int16_t& p = data[DEZIGZAG[k]];
+                if (p != 0)
+                {
+                    correct(p);
+                }
+            }
+            return true;
+        }
+        int k = specStart;
+        do
+        {
+            int const rs = decodeSymbol(table);
+            if (rs < 0)
+            {
+                return false;
+            }
+            int size = rs & 15, run = rs >> 4;
+            int16_t value = 0;
+            if (size == 0)
+            {
+                if (run < 15)
+                {
+                    eobRun_ = (1 << run) - 1;
+                    if (run != 0)
+                    {
+                        eobRun_ += receiveBits(run);
+                    }
+                    run = 64; // the rest of the band only takes correction bits
+                }
+                // run == 15: sixteen zero coefficients are skipped, the sixteenth by the "value" 0 below
+            }
+            else
+            {
+                if (size != 1)
+                {
+                    return false;
+                }
+                value = getBit() != 0 ? bit : static_cast<int16_t>(-bit);
+            }
+            while (k <= specEnd)
+            {
+                int16_t& p = data[DEZIGZAG[k++]];
+                if (p != 0)
+                {
+                    correct(p);
+                }
+                else
+                {
+                    if (run == 0)
+                    {
+                        p = value;
+                        break;
+                    }
+                    run--;
+                }
+            }
+        } while (k <= specEnd);
+        return true;
+    }
+    void finishProgressive()
+    {
+        for (Component& c : components_)
+        {
+            if (!dequantPresent_[c.tq])
+            {
+                continue;
+            }
+            const uint16_t* dq = dequant_[c.tq];
+            int const bw = (c.x + 7) >> 3, bh = (c.y + 7) >> 3;
+            for (int j = 0; j < bh; j++)
+            {
+                for (int i = 0; i < bw; i++)
+                {
+                    int16_t* data = c.coefficients.data() + 64 * (static_cast<size_t>(i) + static_cast<size_t>(j) * static_cast<size_t>(c.coefficientWidth));
+                    for (int k = 0; k < 64; k++)
+                    {
+                        data[k] = static_cast<int16_t>(static_cast<unsigned>(static_cast<int>(data[k])) * dq[k]);
+                    }
+                    idct(c.data.data() + static_cast<size_t>(c.w2) * static_cast<size_t>(j * 8) + static_cast<size_t>(i * 8), c.w2, data);
+                }
+            }
         }
     }
 
@@ -679,17 +870,32 @@ class Decoder
             }
             found->td = tables >> 4;
             found->ta = tables & 15;
-            if (!dc_[found->td].present || !ac_[found->ta].present || !dequantPresent_[found->tq])
+            order.push_back(found);
+        }
+        int const specStart = seg[1 + 2 * n], specEnd = seg[2 + 2 * n], high = seg[3 + 2 * n] >> 4, low = seg[3 + 2 * n] & 15;
+        if (progressive_)
+        {
+            if (specStart > 63 || specEnd > 63 || specStart > specEnd || high > 13 || low > 13 || (specStart == 0 && specEnd != 0) ||
+                (specStart != 0 && n != 1))
+            {
+                why = "bad SOS spectral selection for a progressive JPEG";
+                return false;
+            }
+        }
+        else if (specStart != 0 || specEnd != 63 || high != 0 || low != 0)
+        {
+            why = "bad SOS spectral selection for a sequential JPEG";
+            return false;
+        }
+        for (Component* c : order)
+        {
+            // a progressive DC scan needs no AC table and an AC scan no DC table; the quantisation table may even follow
+            bool const needDc = !progressive_ || (specStart == 0 && high == 0), needAc = !progressive_ || specStart != 0;
+            if ((needDc && !dc_[c->td].present) || (needAc && !ac_[c->ta].present) || (!progressive_ && !dequantPresent_[c->tq]))
             {
                 why = "JPEG scan refers to a table that was not defined";
                 return false;
             }
-            order.push_back(found);
-        }
-        if (seg[1 + 2 * n] != 0 || seg[2 + 2 * n] != 63 || seg[3 + 2 * n] != 0)
-        {
-            why = "bad SOS spectral selection for a sequential JPEG";
-            return false;
         }
         resetEntropy();
         exhausted_ = false;
@@ -717,12 +923,24 @@ class Decoder
             {
                 for (int i = 0; i < bw; i++)
                 {
-                    if (!decodeBlock(c, block))
+                    if (progressive_)
                     {
-                        why = "corrupt JPEG entropy data";
-                        return false;
+                        int16_t* data = c.coefficients.data() + 64 * (static_cast<size_t>(i) + static_cast<size_t>(j) * static_cast<size_t>(c.coefficientWidth));
+                        if (!(specStart == 0 ? decodeProgressiveDc(c, data, high, low) : decodeProgressiveAc(c, data, specStart, specEnd, high, low)))
+                        {
+                            why = "corrupt JPEG entropy data";
+                            return false;
+                        }
                     }
-                    idct(c.data.data() + static_cast<size_t>(c.w2) * static_cast<size_t>(j * 8) + static_cast<size_t>(i * 8), c.w2, block);
+                    else
+                    {
+                        if (!decodeBlock(c, block))
+                        {
+                            why = "corrupt JPEG entropy data";
+                            return false;
+                        }
+                        idct(c.data.data() + static_cast<size_t>(c.w2) * static_cast<size_t>(j * 8) + static_cast<size_t>(i * 8), c.w2, block);
+                    }
                     if (--todo <= 0)
                     {
                         if (!restart())
@@ -746,12 +964,23 @@ class Decoder
                         {
                             for (int x = 0; x < c->h; x++)
                             {
+                                size_t const bx = static_cast<size_t>((i * c->h + x) * 8), by = static_cast<size_t>((j * c->v + y) * 8);
+                                if (progressive_)
+                                {
+                                    // interleaved progressive scans carry DC only (checked above)
+                                    int16_t* data = c->coefficients.data() + 64 * (bx / 8 + (by / 8) * static_cast<size_t>(c->coefficientWidth));
+                                    if (!decodeProgressiveDc(*c, data, high, low))
+                                    {
+                                        why = "corrupt JPEG entropy data";
+                                        return false;
+                                    }
+                                    continue;
+                                }
                                 if (!decodeBlock(*c, block))
                                 {
                                     why = "corrupt JPEG entropy data";
                                     return false;
                                 }
-                                size_t const bx = static_cast<size_t>((i * c->h + x) * 8), by = static_cast<size_t>((j * c->v + y) * 8);
                                 idct(c->data.data() + static_cast<size_t>(c->w2) * by + bx, c->w2, block);
                             }
                         }

@@ -119,10 +119,23 @@ class _Bits:
             self.put((1 << (8 - self.n)) - 1, 8 - self.n)
 
 
+def default_progressive_script(n):
+    """(kind, components, Ss, Se, Ah, Al): DC with a point transform, two AC bands, then successive-approximation refinements."""
+    comps = list(range(n))
+    script = [("dc", comps, 0, 0, 0, 1)]
+    script += [("ac", [k], 1, 5, 0, 2) for k in comps]
+    script += [("ac", [k], 6, 63, 0, 2) for k in comps]
+    script += [("ac", [k], 1, 63, 2, 1) for k in comps]
+    script += [("dc", comps, 0, 0, 1, 0)]
+    script += [("ac", [k], 1, 63, 1, 0) for k in comps]
+    return script
+
+
 def encode(image, sampling=((2, 2), (1, 1), (1, 1)), quality=85, restart=0, interleaved=True, jfif=True, rgb_ids=False,
-           q16=False, adobe_transform=None, comment=None):
+           q16=False, adobe_transform=None, comment=None, progressive=None):
     """image: uint8 [h, w, 3] (RGB) or [h, w] (grey). With rgb_ids the three planes are stored as they are under the
-    component ids 'R', 'G', 'B'; otherwise RGB is converted to YCbCr (JFIF)."""
+    component ids 'R', 'G', 'B'; otherwise RGB is converted to YCbCr (JFIF). progressive: None (baseline), True (the
+    default scan script) or a scan script (default_progressive_script)."""
     img = np.asarray(image)
     h, w = img.shape[:2]
     if img.ndim == 2:
@@ -206,6 +219,11 @@ def encode(image, sampling=((2, 2), (1, 1), (1, 1)), quality=85, restart=0, inte
                     out.append(("ac", k, 0, 0, 0))
         return out
 
+    if progressive:
+        script = default_progressive_script(n) if progressive is True else progressive
+        return _write_progressive(blocks, sampling, tables, comp_tq, ids, h, w, hmax, vmax, mx, my, restart, script, jfif and not rgb_ids,
+                                  adobe_transform, scan_units)
+
     scans = [list(range(n))] if (interleaved or n == 1) else [[k] for k in range(n)]
     scan_symbols = [symbols_of(s) for s in scans]
     # one DC and one AC table per table class (luma / chroma), optimal for this file
@@ -259,6 +277,146 @@ def encode(image, sampling=((2, 2), (1, 1), (1, 1)), quality=85, restart=0, inte
                 bits.put(s[3], s[4])
         bits.align()
         out += bits.out
+    return bytes(out + b"\xff\xd9")
+
+
+def _point(v, al):
+    """AC point transform: division by 2^al that rounds towards zero (T.81 G.1.2.2)"""
+    v = int(v)
+    return (abs(v) >> al) * (1 if v >= 0 else -1)
+
+
+def _write_progressive(blocks, sampling, tables, comp_tq, ids, h, w, hmax, vmax, mx, my, restart, script, jfif, adobe_transform, scan_units):
+    """T.81 annex G: spectral selection + successive approximation, one DHT pair (optimal, table 0) in front of every scan."""
+    n = len(blocks)
+    out = bytearray(b"\xff\xd8")
+    if jfif and adobe_transform is None:
+        out += b"\xff\xe0" + struct.pack(">H5sHBHHBB", 16, b"JFIF\0", 0x0101, 0, 1, 1, 0, 0)
+    if adobe_transform is not None:
+        out += b"\xff\xee" + struct.pack(">H5sHHHB", 14, b"Adobe", 100, 0, 0, adobe_transform)
+    for t in sorted(set(comp_tq)):
+        zz = [int(tables[t][ZIGZAG[i]]) for i in range(64)]
+        if max(zz) > 255:
+            out += b"\xff\xdb" + struct.pack(">HB", 2 + 1 + 128, 0x10 | t) + b"".join(struct.pack(">H", v) for v in zz)
+        else:
+            out += b"\xff\xdb" + struct.pack(">HB", 2 + 1 + 64, t) + bytes(zz)
+    out += b"\xff\xc2" + struct.pack(">HBHHB", 8 + 3 * n, 8, h, w, n)
+    for k in range(n):
+        out += bytes([ids[k], (sampling[k][0] << 4) | sampling[k][1], comp_tq[k]])
+    if restart:
+        out += b"\xff\xdd" + struct.pack(">HH", 4, restart)
+
+    for kind, comps, ss, se, ah, al in script:
+        items, count, rst = [], 0, 0  # ("sym", v) | ("bits", v, n) | ("rst", k)
+        pred = {k: 0 for k in comps}
+        eobrun, pending = 0, []  # AC: end-of-band run and the correction bits that follow its symbol
+
+        def flush_eobrun():
+            nonlocal eobrun, pending
+            if eobrun:
+                nb = eobrun.bit_length() - 1
+                items.append(("sym", nb << 4))
+                if nb:
+                    items.append(("bits", eobrun - (1 << nb), nb))
+                eobrun = 0
+            for b in pending:
+                items.append(("bits", b, 1))
+            pending = []
+
+        for unit in scan_units(comps):
+            if restart and count == restart:
+                flush_eobrun()
+                items.append(("rst", rst))
+                rst, count, pred = (rst + 1) & 7, 0, {k: 0 for k in comps}
+            count += 1
+            for k, block in unit:
+                if kind == "dc":
+                    v = int(block[0]) >> al  # arithmetic shift (T.81 G.1.2.1)
+                    if ah == 0:
+                        diff = v - pred[k]
+                        pred[k] = v
+                        c = _category(diff)
+                        items.append(("sym", c))
+                        if c:
+                            items.append(("bits", _extra(diff, c), c))
+                    else:
+                        items.append(("bits", v & 1, 1))
+                    continue
+                zz = [int(block[ZIGZAG[i]]) for i in range(64)]
+                if ah == 0:
+                    run = 0
+                    for i in range(ss, se + 1):
+                        t = _point(zz[i], al)
+                        if t == 0:
+                            run += 1
+                            continue
+                        flush_eobrun()
+                        while run > 15:
+                            items.append(("sym", 0xF0))
+                            run -= 16
+                        c = _category(t)
+                        items.append(("sym", (run << 4) | c))
+                        items.append(("bits", _extra(t, c), c))
+                        run = 0
+                    if run:
+                        eobrun += 1
+                        if eobrun == 0x7FFF:
+                            flush_eobrun()
+                    continue
+                # refinement (T.81 figure G.7): newly non-zero coefficients have magnitude 1 after the point transform
+                absval = [abs(zz[i]) >> al for i in range(64)]
+                eob = max([i for i in range(ss, se + 1) if absval[i] == 1], default=0)
+                run, corrections = 0, []
+                for i in range(ss, se + 1):
+                    t = absval[i]
+                    if t == 0:
+                        run += 1
+                        continue
+                    while run > 15 and i <= eob:
+                        flush_eobrun()
+                        items.append(("sym", 0xF0))
+                        run -= 16
+                        items.extend(("bits", b, 1) for b in corrections)
+                        corrections = []
+                    if t > 1:
+                        corrections.append(t & 1)
+                        continue
+                    flush_eobrun()
+                    items.append(("sym", (run << 4) | 1))
+                    items.append(("bits", 0 if zz[i] < 0 else 1, 1))
+                    items.extend(("bits", b, 1) for b in corrections)
+                    corrections, run = [], 0
+                if run or corrections:
+                    eobrun += 1
+                    pending.extend(corrections)
+                    if eobrun == 0x7FFF or len(pending) > 900:
+                        flush_eobrun()
+        flush_eobrun()
+
+        freq = {}
+        for it in items:
+            if it[0] == "sym":
+                freq[it[1]] = freq.get(it[1], 0) + 1
+        codes = None
+        if freq:
+            bits, symbols = _optimal_table(freq)
+            codes = _codes(bits, symbols)
+            out += b"\xff\xc4" + struct.pack(">HB", 2 + 1 + 16 + len(symbols), 0x10 if kind == "ac" else 0) + bytes(bits) + bytes(symbols)
+        out += b"\xff\xda" + struct.pack(">HB", 6 + 2 * len(comps), len(comps))
+        for k in comps:
+            out += bytes([ids[k], 0])
+        out += bytes([ss, se, (ah << 4) | al])
+        stream = _Bits()
+        for it in items:
+            if it[0] == "rst":
+                stream.align()
+                stream.out += bytes([0xFF, 0xD0 + it[1]])
+            elif it[0] == "sym":
+                stream.put(*codes[it[1]])
+            else:
+                stream.put(it[1], it[2])
+        stream.align()
+        out += stream.out
     return bytes(out + b"\xff\xd9")
 
 
@@ -354,14 +512,69 @@ def _extend(v, n):
     return v - (1 << n) + 1 if n and v < (1 << (n - 1)) else v
 
 
+def _progressive_ac(reader, table, data, ss, se, ah, al, eobrun):
+    """one block of a progressive AC scan (T.81 G.1.2.2 / G.1.2.3); returns the updated end-of-band run"""
+    if ah == 0:
+        if eobrun:
+            return eobrun - 1
+        k = ss
+        while k <= se:
+            rs = _decode_symbol(reader, table)
+            r, sz = rs >> 4, rs & 15
+            if sz == 0:
+                if r < 15:
+                    return (1 << r) + (reader.bits(r) if r else 0) - 1
+                k += 16
+                continue
+            k += r
+            data[ZIGZAG[k]] = _int16(_extend(reader.bits(sz), sz) * (1 << al))
+            k += 1
+        return 0
+    bit = 1 << al
+
+    def correct(i):
+        if reader.bit1() and (data[i] & bit) == 0:
+            data[i] = _int16(data[i] + bit if data[i] > 0 else data[i] - bit)
+
+    if eobrun:
+        for k in range(ss, se + 1):
+            if data[ZIGZAG[k]]:
+                correct(ZIGZAG[k])
+        return eobrun - 1
+    k = ss
+    while k <= se:
+        rs = _decode_symbol(reader, table)
+        r, sz = rs >> 4, rs & 15
+        value = 0
+        if sz == 0:
+            if r < 15:
+                eobrun = (1 << r) - 1 + (reader.bits(r) if r else 0)
+                r = 64
+        else:
+            assert sz == 1
+            value = bit if reader.bit1() else -bit
+        while k <= se:
+            i = ZIGZAG[k]
+            k += 1
+            if data[i]:
+                correct(i)
+            else:
+                if r == 0:
+                    data[i] = value
+                    break
+                r -= 1
+    return eobrun
+
+
 def decode(data):
-    """baseline JPEG bytes -> uint8 [h, w, 4] as stb_image returns it for a 4-channel request"""
+    """baseline or progressive JPEG bytes -> uint8 [h, w, 4] as stb_image returns it for a 4-channel request"""
     data = bytes(data)
     assert data[:2] == b"\xff\xd8"
     pos = 2
     quant, huff, comps, restart = {}, {}, [], 0
     jfif, adobe, w = False, -1, 0
     planes = {}
+    progressive, coefs = False, {}
     while True:
         assert data[pos] == 0xFF
         while data[pos + 1] == 0xFF:
@@ -403,7 +616,8 @@ def decode(data):
                 seg = seg[17 + total :]
         elif marker == 0xDD:
             restart = struct.unpack(">H", seg)[0]
-        elif marker == 0xC0 or marker == 0xC1:
+        elif marker in (0xC0, 0xC1, 0xC2):
+            progressive = marker == 0xC2
             _, h, w, n = struct.unpack(">BHHB", seg[:6])
             comps = [{"id": seg[6 + 3 * i], "h": seg[7 + 3 * i] >> 4, "v": seg[7 + 3 * i] & 15, "tq": seg[8 + 3 * i]} for i in range(n)]
             hmax, vmax = max(c["h"] for c in comps), max(c["v"] for c in comps)
@@ -411,8 +625,10 @@ def decode(data):
             for c in comps:
                 c["x"], c["y"] = -(-w * c["h"] // hmax), -(-h * c["v"] // vmax)
                 planes[c["id"]] = np.zeros((my * c["v"] * 8, mx * c["h"] * 8), np.uint8)
+                coefs[c["id"]] = {}
         elif marker == 0xDA:
             ns = seg[0]
+            ss, se, ah, al = seg[1 + 2 * ns], seg[2 + 2 * ns], seg[3 + 2 * ns] >> 4, seg[3 + 2 * ns] & 15
             order = []
             for i in range(ns):
                 c = next(c for c in comps if c["id"] == seg[1 + 2 * i])
@@ -445,8 +661,21 @@ def decode(data):
             for s, first in enumerate(range(0, len(units), interval)):
                 reader = _Reader(segments[s] if s < len(segments) else b"")
                 pred = {c["id"]: 0 for c in order}
+                eobrun = 0
                 for unit in units[first : first + interval]:
                     for c, by, bx in unit:
+                        if progressive:
+                            cf = coefs[c["id"]].setdefault((by, bx), [0] * 64)
+                            if ss == 0:
+                                if ah == 0:
+                                    t = _decode_symbol(reader, huff[(0, c["td"])])
+                                    pred[c["id"]] += _extend(reader.bits(t), t)
+                                    cf[0] = _int16(pred[c["id"]] * (1 << al))
+                                elif reader.bit1():
+                                    cf[0] = _int16(cf[0] + (1 << al))
+                            else:
+                                eobrun = _progressive_ac(reader, huff[(1, c["ta"])], cf, ss, se, ah, al, eobrun)
+                            continue
                         dq = quant[c["tq"]]
                         block = [0] * 64
                         t = _decode_symbol(reader, huff[(0, c["td"])])
@@ -465,6 +694,11 @@ def decode(data):
                             block[ZIGZAG[k]] = _int16(_extend(reader.bits(sz), sz) * dq[ZIGZAG[k]])
                             k += 1
                         planes[c["id"]][by * 8 : by * 8 + 8, bx * 8 : bx * 8 + 8] = _idct_block(block)
+    if progressive:
+        for c in comps:
+            dq = quant[c["tq"]]
+            for (by, bx), cf in coefs[c["id"]].items():
+                planes[c["id"]][by * 8 : by * 8 + 8, bx * 8 : bx * 8 + 8] = _idct_block([_int16(cf[i] * dq[i]) for i in range(64)])
     # upsampling (stb_image's resamplers) and colour conversion
     n = len(comps)
     full = []

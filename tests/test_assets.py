@@ -156,6 +156,41 @@ def test_jpeg_baseline_sampling_restart_and_scan_layouts(sampling, restart, inte
     assert np.abs(got[..., :3].astype(int) - img.astype(int)).mean() < 2.0
 
 
+@pytest.mark.parametrize("sampling", ["444", "420", "mixed", "411"])
+@pytest.mark.parametrize("restart", [0, 2])
+def test_jpeg_progressive_equals_the_baseline_file_of_the_same_coefficients(sampling, restart):
+    """T.81 annex G. The encoder writes the same quantised coefficients once sequentially and once as progressive scans
+    (spectral selection, successive approximation with DC and AC refinement passes, end-of-band runs): both files must
+    decode to the same picture, and the C++ decoder must agree with the numpy one."""
+    for k, (w, h) in enumerate([(37, 53), (8, 8), (70, 19)]):
+        img = _picture(w, h, 20 + k)
+        kw = dict(sampling=SAMPLINGS[sampling], quality=[85, 50, 95][k], restart=restart)
+        want = jt.decode(jt.encode(img, **kw))
+        n = 3
+        scripts = {
+            "default": True,
+            "spectral selection only": [("dc", [0, 1, 2], 0, 0, 0, 0)] + [("ac", [c], a, b, 0, 0) for c in range(n) for a, b in [(1, 2), (3, 20), (21, 63)]],
+            "separate dc scans, deep approximation": [("dc", [c], 0, 0, 0, 2) for c in range(n)] + [("ac", [c], 1, 63, 0, 3) for c in range(n)] +
+                                                     [("ac", [c], 1, 63, 3, 2) for c in range(n)] + [("dc", [0, 1, 2], 0, 0, 2, 1)] +
+                                                     [("ac", [c], 1, 63, 2, 1) for c in range(n)] + [("dc", [c], 0, 0, 1, 0) for c in range(n)] +
+                                                     [("ac", [c], 1, 63, 1, 0) for c in range(n)],
+        }
+        for name, script in scripts.items():
+            data = jt.encode(img, progressive=script, **kw)
+            assert (jt.decode(data) == want).all(), (name, w, h)
+            assert (assets.decode_image_rgba(data) == want).all(), (name, w, h)
+    grey = _picture(29, 31, 5)[..., 0]
+    data = jt.encode(grey, sampling=[(1, 1)], progressive=True, restart=restart)
+    assert (assets.decode_image_rgba(data) == jt.decode(jt.encode(grey, sampling=[(1, 1)], restart=restart))).all()
+    # an interrupted progressive file (the usual reason to write one) still gives the coarse picture
+    img = _picture(40, 40, 8)
+    data = jt.encode(img, sampling=SAMPLINGS[sampling], progressive=True, restart=restart)
+    second_scan = data.index(b"\xff\xda", data.index(b"\xff\xda") + 2)
+    coarse = assets.decode_image_rgba(data[:second_scan] + b"\xff\xd9")
+    fine = assets.decode_image_rgba(data)
+    assert coarse.shape == fine.shape and np.abs(coarse[..., :3].astype(int) - fine[..., :3].astype(int)).mean() < 40
+
+
 def test_jpeg_colour_spaces_and_table_precisions():
     img = _picture(41, 23, 4)
     grey = img[..., 1]
@@ -179,7 +214,7 @@ def test_jpeg_what_is_refused_and_what_is_tolerated():
     img = _picture(33, 17, 2)
     data = jt.encode(img, restart=2)
     sof = data.index(b"\xff\xc0")
-    for bad, why in [(data[:sof] + b"\xff\xc2" + data[sof + 2 :], "progressive"), (data[:sof] + b"\xff\xc9" + data[sof + 2 :], "arithmetic"),
+    for bad, why in [(data[:sof] + b"\xff\xc2" + data[sof + 2 :], "spectral selection"), (data[:sof] + b"\xff\xc9" + data[sof + 2 :], "arithmetic"),
                      (data[: sof + 4] + b"\x0c" + data[sof + 5 :], "8-bit"), (data[:2] + data[sof:], "not defined"),
                      (data[:sof] + data[sof + 19 :], "frame header"), (b"\xff\xd8\xff\xd9", "without image data")]:
         with pytest.raises(assets.AssetError, match=why):
