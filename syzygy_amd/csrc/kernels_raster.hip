@@ -504,8 +504,9 @@ __global__ __launch_bounds__(256) void k_raster_tile(szg_image depth, szg_image 
         edgeFunctions(t, px, py, e);
         float d;
         bool const ok = fragmentDepth(t, e, d);
-        // GREATER in submission order: the walk order is arbitrary, so an equal depth goes to the earlier primitive
-        if (coversPixel(t, e) && ok && (d > best || (d == best && p < winner)))
+        // GREATER in submission order: the walk order is arbitrary, so an equal depth goes to the earlier primitive — among
+        // fragments; a depth equal to the clear value (0, also as an underflow of a huge primitive) is not GREATER than it
+        if (coversPixel(t, e) && ok && (d > best || (d == best && winner != 0xFFFFFFFFu && p < winner)))
         {
             best = d;
             winner = p;

@@ -402,6 +402,28 @@ def test_gbuffer_raster_fullscreen_fan_is_watertight(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("z", [0.0, -0.0, 1.0e-45])
+def test_gbuffer_raster_depth_equal_to_the_clear_value_is_not_a_fragment(gpu, z):
+    """GREATER against the cleared 0 (deferred.cpp:383-386): a primitive whose depth is exactly 0 (in the wild: the underflow
+    of a huge, far primitive; found by tools/random_sweep_raster.py seed 21607) covers pixels but produces no fragment,
+    in front of or behind a real one; the smallest positive depth does."""
+    W, H = 67, 45
+    fan = _fullscreen_fan(z=z)
+    near = _fullscreen_fan(z=0.25, centre=(-0.3, 0.4))
+    material = meshes.default_material()
+    for order in ([fan], [fan, near], [near, fan]):
+        ms = [meshes.MeshInstanced(v, idx, [(0, len(idx), material)], [meshes.transform_matrix()]) for v, idx in order]
+        planes, depth = _raster_gpu(gpu, W, H, _identity_camera(), ms)
+        want = ob.HostFrame(W, H)
+        ob.gbuffer_raster(want, abi.Rect(0, 0, W, H), None, _identity_camera(), ms, threads=4)
+        assert (depth.view(np.uint32) == want.depth.view(np.uint32)).all()
+        _planes_equal(planes, want.planes())
+        if len(order) == 1:
+            written = planes["diffuse"][..., 3] == 1
+            assert written.all() if z > 0 else not written.any()
+
+
+@pytest.mark.gpu
 def test_gbuffer_raster_row_tiles_bit_exact(gpu):
     W, H = 200, 120
     inp = util.Inputs(W, H)
