@@ -275,9 +275,14 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
         // exact zero that may be skipped — unless the environment could be NaN or inf (0 * NaN = NaN poisons the pixel in
         // the reference). It cannot when the extinction is bounded away from 0 along every ray of the shell
         // (Atm::extModerate), the transmittance LUT is moderate, and both the camera (whose sky-view LUT is sampled)
-        // and the surface (origin of the reflection ray) lie inside the shell; otherwise the term is evaluated.
+        // and the surface (origin of the reflection ray) lie inside the shell, and the reflection direction itself is finite
+        // (it is built from the G-buffer normal; found by tools/random_sweep_mesh_frames.py: a NaN normal from a degenerate
+        // triangle leaves the sun term at 0 through the clamps but makes the environment sample NaN); otherwise the term
+        // is evaluated.
         float const cameraR2 = dot(position, position), surfaceR2 = dot(surfacePosition, surfacePosition);
-        bool const environmentFinite = a.extModerate && L.moderate && inRange(cameraR2, a.extFloor2, a.extCeil2) &&
+        float const nBig = 0x1p60f;
+        bool const normalFinite = fabsf(m.normal.x) <= nBig && fabsf(m.normal.y) <= nBig && fabsf(m.normal.z) <= nBig;
+        bool const environmentFinite = a.extModerate && L.moderate && normalFinite && inRange(cameraR2, a.extFloor2, a.extCeil2) &&
                                        inRange(surfaceR2, a.extFloor2, a.extCeil2);
         if (m.metallic != 0.0f || !environmentFinite)
         {

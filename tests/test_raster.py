@@ -537,3 +537,59 @@ def test_frame_from_real_meshes_matches_oracle_chain(gpu):
     assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
     deferred.cleanup()
     sky.destroy()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1465, 1484, 1497])
+def test_frame_from_hostile_meshes_poisons_the_same_pixels(gpu, seed):
+    """The whole chain on degenerate geometry (tools/random_sweep_mesh_frames.py found these): a zero-area or constant-uv
+    triangle writes a NaN normal into the G-buffer. The sun term survives through its clamps, but the metal reflection's
+    environment sample is NaN and `0 * NaN` poisons the pixel in the reference even for metallic == 0, so the composite
+    may not skip that term. fp32 frame bit-identical including the NaN pattern."""
+    torch = gpu.torch
+    from syzygy_amd import lib, scene
+
+    rng = np.random.default_rng(seed)
+    W, H, DIM = int(rng.integers(16, 120)), int(rng.integers(9, 70)), int(rng.choice([32, 96]))
+    cam = scene.default_camera()
+    cam.cameraPosition[:] = [float(rng.uniform(-30, 30)), float(rng.uniform(-30, -1)), float(rng.uniform(-40, 20))]
+    cam.eulerAngles[:] = [float(rng.uniform(-1.2, 1.2)), float(rng.uniform(-3.1, 3.1)), 0.0]
+    cam.fovDegrees = float(rng.uniform(30.0, 110.0))
+    spots_n = int(rng.integers(0, 4))
+    inp = util.Inputs(W, H, elevation_degrees=float(rng.uniform(-8.0, 80.0)), spots=max(spots_n, 1), camera=cam)
+    assert int(rng.integers(0, 3)) == 2
+    ms = _hostile_scene(seed, bool(rng.integers(0, 2)))
+    cameras = _cameras(gpu, inp.cam)
+    atmospheres = gpu.pl.TStagedBuffer(abi.AtmospherePacked, 1)
+    atmospheres.push(inp.atm)
+    atmospheres.recordCopyToDevice()
+    lights = gpu.pl.TStagedBuffer(abi.DirectionalLightPacked, 2)
+    lights.push([inp.sun, inp.moon])
+    lights.recordCopyToDevice()
+    target = gpu.pl.SceneTexture(W, H, debug=True)
+    deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=max(spots_n, 1), max_shadow_maps=2 + spots_n, shadow_map_dim=DIM)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(64, 16), skyview_extent=(64, 32))
+    deferred.recordDrawCommandsMeshes(None, inp.rect, target, 1, lights, inp.spots if spots_n else None, 0, cameras, ms)
+    sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    got, got_q = target.debug.cpu().numpy(), target.color_numpy()
+
+    maps = []
+    for light in [inp.sun, inp.moon] + [inp.spots[i] for i in range(spots_n)]:
+        pv = abi.Mat4()
+        lib().szg_mat4_mul(C.byref(light.projection), C.byref(light.view), C.byref(pv))
+        maps.append(ob.shadow_raster(pv, DIM, ms, threads=8))
+    images = (abi.Image * len(maps))(*[ob.host_image(m, abi.SZG_FORMAT_D32_SFLOAT) for m in maps])
+    host_maps = abi.ShadowMaps(len(maps), 0, C.cast(images, C.POINTER(abi.Image)))
+    frame = ob.HostFrame(W, H)
+    ob.gbuffer_raster(frame, inp.rect, None, inp.cam, ms, threads=8)
+    ob.lights(frame, inp.rect, None, host_maps, inp.cam, inp.dirs, 2, 1, inp.spots, spots_n, threads=8)
+    tlut = ob.transmittance_lut(inp.atm, 64, 16, threads=8)
+    slut = ob.skyview_lut(inp.atm, inp.cam, tlut, 64, 32, threads=8)
+    ob.composite(frame, inp.rect, None, host_maps, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=8)
+    assert np.isnan(frame.planes()["normal"]).any() and np.isnan(frame.debug).any()
+    same = (got.view(np.uint32) == frame.debug.view(np.uint32)) | (np.isnan(got) & np.isnan(frame.debug))
+    assert same.all(), f"{(~same).sum()} fp32 values differ; NaNs {np.isnan(got).sum()} vs {np.isnan(frame.debug).sum()}"
+    assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+    deferred.cleanup()
+    sky.destroy()
