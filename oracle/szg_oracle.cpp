@@ -189,7 +189,9 @@ inline float half_to_float(uint16_t h)
     }
     else if (exp == 31)
     {
-        bits = sign | 0x7F800000u | (man << 13);
+        // inf, or NaN with its payload; a signalling NaN comes out quiet, as IEEE 754 conversions (and the hardware ones:
+        // v_cvt_f32_f16, F16C) deliver it — otherwise fmaxf / fminf downstream would treat it differently from a quiet one
+        bits = sign | 0x7F800000u | (man << 13) | (man != 0 ? 0x00400000u : 0u);
     }
     else
     {
