@@ -282,8 +282,11 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
         float const cameraR2 = dot(position, position), surfaceR2 = dot(surfacePosition, surfacePosition);
         float const nBig = 0x1p60f;
         bool const normalFinite = fabsf(m.normal.x) <= nBig && fabsf(m.normal.y) <= nBig && fabsf(m.normal.z) <= nBig;
-        bool const environmentFinite = a.extModerate && L.moderate && normalFinite && inRange(cameraR2, a.extFloor2, a.extCeil2) &&
-                                       inRange(surfaceR2, a.extFloor2, a.extCeil2);
+        // Both horizon angles asin(Rp / r) must exist: the camera's (every texel of the sky-view LUT depends on it) and the
+        // surface's (where the LUT is sampled from); same expressions as skyview_LUT.comp:106-112 and camera.comp:75-77.
+        bool const aboveGround = (a.planetRadius / length(position)) <= 1.0f && fractionOfSunVisible <= 1.0f;
+        bool const environmentFinite = a.extModerate && a.sunSane && L.moderate && normalFinite && aboveGround &&
+                                       inRange(cameraR2, a.extFloor2, a.extCeil2) && inRange(surfaceR2, a.extFloor2, a.extCeil2);
         if (m.metallic != 0.0f || !environmentFinite)
         {
             hasReflection = true;

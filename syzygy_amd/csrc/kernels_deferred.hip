@@ -262,11 +262,14 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
     }
     {
         float const lo = 0x1p-30f, hi = 0x1p30f;
-        r.leanOK = (r.isSpot != 0u && inRange(r.falloffDistance, lo, hi) && inRange(r.falloffFactor, lo, hi)) ? 1u : 0u;
-        // A spot light's term for a pixel outside its cone is (colour * strength / falloff) * 0 * brdf: an exact zero only
-        // if every factor is finite. The light's own factors are checked here, the pixel's in k_lights.
-        bool const finite = fabsf(r.colorStrength[0]) <= hi && fabsf(r.colorStrength[1]) <= hi && fabsf(r.colorStrength[2]) <= hi;
-        r.pad[0] = (r.leanOK != 0u && finite) ? 1u : 0u; // "cullable"
+        // colour * strength is the numerator of lean divisions (an infinite one would come out NaN instead of inf) and a
+        // factor of the culled term: a spot light's term for a pixel outside its cone is (colour * strength / falloff) * 0 *
+        // brdf, an exact zero only if every factor is finite. The light's own factors are checked here, the pixel's in k_lights.
+        bool const finite = fabsf(r.colorStrength[0]) <= hi && fabsf(r.colorStrength[1]) <= hi && fabsf(r.colorStrength[2]) <= hi &&
+                            fabsf(r.position[0]) <= hi && fabsf(r.position[1]) <= hi && fabsf(r.position[2]) <= hi &&
+                            fabsf(r.dir[0]) <= 2.0f && fabsf(r.dir[1]) <= 2.0f && fabsf(r.dir[2]) <= 2.0f;
+        r.leanOK = (r.isSpot != 0u && finite && inRange(r.falloffDistance, lo, hi) && inRange(r.falloffFactor, lo, hi)) ? 1u : 0u;
+        r.pad[0] = r.leanOK; // "cullable"
     }
     r.pad[1] = 0u;
     out[i] = r;

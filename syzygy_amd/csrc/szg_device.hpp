@@ -326,6 +326,10 @@ struct Atm
     // the extinction sum stays in [2^-40, 2^52] for radii in [sqrt(extFloor2), sqrt(extCeil2)] (lean division of the
     // in-scatter integral): coefficients <= 2^10, densities <= e^27, Rayleigh scattering alone >= 2^-40 at the shell's top
     bool extModerate;
+    // the sun direction is a unit vector to 1 % and the sun's angular radius a sane positive number: with extModerate and a
+    // moderate transmittance LUT, what makes every environment sample (sky-view LUT, sun disc, ground march) finite for
+    // any finite ray — the phase functions see a true cosine (phaseMie's pow(1 + g^2 - 2 g c, 1.5) is NaN for c > 1.025)
+    bool sunSane;
     float extFloor2, extCeil2; // Rayleigh / Mie scattering and Rayleigh absorption carry no sign bit: partial sums are never -0
 };
 SZG_DEV bool plusZero3(V3 v)
@@ -357,8 +361,12 @@ SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
     // Preconditions of the lean ops that depend only on the atmosphere: radii, H and density scales of moderate
     // magnitude, and the x_mu denominator rho + H - (Ra - r) bounded away from 0 for every r >= 0.9 Rp.
     float const lo = 0x1p-30f, hi = 0x1p30f;
+    // The density scales must also be large against the rounding of a radius (a few ulps of Rp): the zero-coefficient
+    // shortcuts and expX<true> count on exp(-altitude / scale) staying finite for samples the lean floor admits, and an
+    // altitude that comes out a few ulps below that floor must not be e^100 scale heights deep.
+    float const scaleFloor = a.planetRadius * 0x1p-18f;
     a.lean = inRange(a.planetRadius, lo, hi) && inRange(a.atmosphereRadius, lo, hi) && inRange(a.H, lo, hi) &&
-             inRange(a.densityScaleRayleigh, lo, hi) && inRange(a.densityScaleMie, lo, hi) &&
+             inRange(a.densityScaleRayleigh, fmaxf(lo, scaleFloor), hi) && inRange(a.densityScaleMie, fmaxf(lo, scaleFloor), hi) &&
              (a.H - a.atmosphereRadius + 0.9f * a.planetRadius >= 0x1p-20f);
     // coefficients finite and of moderate magnitude: no NaN / inf can enter the extinction sum on a lean path
     // (expX<true> relies on that)
@@ -387,6 +395,11 @@ SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
         }
         a.extModerate = a.lean && a.signClearCoefficients && signClear3(a.scatteringOzone) && signClear3(a.absorptionOzone) && small &&
                         inRange(shell, lo, hi) && (minRayleigh * thinnest >= 0x1p-40f);
+        float const sun2 = dot(a.incidentDirectionSun, a.incidentDirectionSun);
+        // (and its azimuth exists: normalize(vec2(-sun.x, -sun.z)) of skyview_LUT.comp:60-61 / camera.comp:113-114 is 0/0 for an
+        // exactly vertical sun)
+        float const sunHorizontal2 = a.incidentDirectionSun.x * a.incidentDirectionSun.x + a.incidentDirectionSun.z * a.incidentDirectionSun.z;
+        a.sunSane = inRange(sun2, 0.98f, 1.02f) && inRange(a.sunAngularRadius, 0x1p-30f, 1.5f) && sunHorizontal2 >= 0x1p-100f;
         float const eFloor = fmaxf(0.9f * a.planetRadius, a.planetRadius - 27.0f * fminf(a.densityScaleRayleigh, a.densityScaleMie));
         float const eCeil = a.atmosphereRadius + shell * 0.005f;
         a.extFloor2 = eFloor * eFloor;
