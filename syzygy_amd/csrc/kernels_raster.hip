@@ -209,16 +209,40 @@ __global__ __launch_bounds__(64) void k_raster_setup(const RasterDraw* __restric
             }
             if (valid)
             {
-                // conservative pixel box: exact projection when every vertex is in front of the eye, else the viewport
+                // Conservative pixel box: the projected triangle plus a margin when every vertex is in front of the eye, else
+                // the viewport. Coverage is DEFINED by the fp32 edge functions (raster.h); their zero lines sit within
+                // |error of e| / |grad e| pixels of the exact edges, and |error of e| <= 2^-22 (A px + B py + C) with A, B, C
+                // the sums of the magnitudes of the products a, b, c are made of (two roundings each, three more in the
+                // evaluation). The margin is 1 px plus what that can move the triangle's outline: a fraction of a pixel for
+                // ordinary triangles, a few pixels for distant tiny ones; beyond 64 px the viewport is used — a camera a
+                // million units away (the edge functions are rounding noise, which the oracle shades too), or a triangle that
+                // projects to (almost) a line, a zero column in the projection say: each edge may be sharp, but where the
+                // three half-planes intersect is decided by rounding.
                 float fx0 = 0.0f, fx1 = (float)W, fy0 = 0.0f, fy1 = (float)H;
-                if (allFront)
+                float margin = 1.0f;
+                bool thick = true;
+#pragma unroll
+                for (int i = 0; i < 3; i++)
+                {
+                    int const j = (i + 1) % 3, k = (i + 2) % 3;
+                    float const A = fabsf(hy[j] * hw[k]) + fabsf(hy[k] * hw[j]);
+                    float const B = fabsf(hx[k] * hw[j]) + fabsf(hx[j] * hw[k]);
+                    float const Cc = fabsf(hx[j] * hy[k]) + fabsf(hx[k] * hy[j]);
+                    float const noise = 0x1p-22f * ((A * ((float)W + 1.0f) + B * ((float)H + 1.0f)) + Cc);
+                    margin = fmaxf(margin, 1.0f + noise / fmaxf(fabsf(r.a[i]), fabsf(r.b[i]))); // (x / 0 = inf, 0 / 0 = NaN: rejected below)
+                    // e_i at vertex i is det / w_i: the triangle's altitude over edge i, in units of e_i. It has an inside that
+                    // the rounding cannot move only if that is several times the noise of e_i.
+                    thick = thick && (fabsf(det) >= 4.0f * noise * fabsf(hw[i]));
+                }
+                bool const boxUsable = margin <= 64.0f && thick;
+                if (allFront && boxUsable)
                 {
                     float const x0 = hx[0] / hw[0], x1 = hx[1] / hw[1], x2 = hx[2] / hw[2];
                     float const y0 = hy[0] / hw[0], y1 = hy[1] / hw[1], y2 = hy[2] / hw[2];
-                    fx0 = fmaxf(fminf(fminf(x0, x1), x2) - 1.0f, 0.0f);
-                    fx1 = fminf(fmaxf(fmaxf(x0, x1), x2) + 1.0f, (float)W);
-                    fy0 = fmaxf(fminf(fminf(y0, y1), y2) - 1.0f, 0.0f);
-                    fy1 = fminf(fmaxf(fmaxf(y0, y1), y2) + 1.0f, (float)H);
+                    fx0 = fmaxf(fminf(fminf(x0, x1), x2) - margin, 0.0f);
+                    fx1 = fminf(fmaxf(fmaxf(x0, x1), x2) + margin, (float)W);
+                    fy0 = fmaxf(fminf(fminf(y0, y1), y2) - margin, 0.0f);
+                    fy1 = fminf(fmaxf(fmaxf(y0, y1), y2) + margin, (float)H);
                 }
                 minX = (int)fx0;
                 minY = (int)fy0;
