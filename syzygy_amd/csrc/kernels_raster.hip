@@ -209,40 +209,51 @@ __global__ __launch_bounds__(64) void k_raster_setup(const RasterDraw* __restric
             }
             if (valid)
             {
-                // Conservative pixel box: the projected triangle plus a margin when every vertex is in front of the eye, else
-                // the viewport. Coverage is DEFINED by the fp32 edge functions (raster.h); their zero lines sit within
-                // |error of e| / |grad e| pixels of the exact edges, and |error of e| <= 2^-22 (A px + B py + C) with A, B, C
-                // the sums of the magnitudes of the products a, b, c are made of (two roundings each, three more in the
-                // evaluation). The margin is 1 px plus what that can move the triangle's outline: a fraction of a pixel for
-                // ordinary triangles, a few pixels for distant tiny ones; beyond 64 px the viewport is used — a camera a
-                // million units away (the edge functions are rounding noise, which the oracle shades too), or a triangle that
-                // projects to (almost) a line, a zero column in the projection say: each edge may be sharp, but where the
-                // three half-planes intersect is decided by rounding.
+                // Conservative pixel box when every vertex is in front of the eye, else the viewport. Coverage is DEFINED by
+                // the fp32 edge functions (raster.h), and |error of e_i| <= noise_i = 2^-22 (A px + B py + C) with A, B, C the sums
+                // of the magnitudes of the products a_i, b_i, c_i are made of (two roundings each, three more in the
+                // evaluation). Every pixel the fp32 test can accept therefore lies in {e_i > -noise_i for all i}: the
+                // triangle T' bounded by the three edge lines pushed out by their noise. The box is the bounding box of T'
+                // (+- 1 px for its own rounding): the projected triangle itself for ordinary primitives, a few pixels more
+                // for distant tiny ones, and — because nearly parallel lines meet far away — the whole viewport where the
+                // edge functions are rounding noise (a camera a million units away) or the triangle projects to a line (a
+                // zero column in the projection): regions the oracle, which tests every pixel, shades too.
                 float fx0 = 0.0f, fx1 = (float)W, fy0 = 0.0f, fy1 = (float)H;
-                float margin = 1.0f;
-                bool thick = true;
+                if (allFront)
+                {
+                    float pushed[3];
 #pragma unroll
-                for (int i = 0; i < 3; i++)
-                {
-                    int const j = (i + 1) % 3, k = (i + 2) % 3;
-                    float const A = fabsf(hy[j] * hw[k]) + fabsf(hy[k] * hw[j]);
-                    float const B = fabsf(hx[k] * hw[j]) + fabsf(hx[j] * hw[k]);
-                    float const Cc = fabsf(hx[j] * hy[k]) + fabsf(hx[k] * hy[j]);
-                    float const noise = 0x1p-22f * ((A * ((float)W + 1.0f) + B * ((float)H + 1.0f)) + Cc);
-                    margin = fmaxf(margin, 1.0f + noise / fmaxf(fabsf(r.a[i]), fabsf(r.b[i]))); // (x / 0 = inf, 0 / 0 = NaN: rejected below)
-                    // e_i at vertex i is det / w_i: the triangle's altitude over edge i, in units of e_i. It has an inside that
-                    // the rounding cannot move only if that is several times the noise of e_i.
-                    thick = thick && (fabsf(det) >= 4.0f * noise * fabsf(hw[i]));
-                }
-                bool const boxUsable = margin <= 64.0f && thick;
-                if (allFront && boxUsable)
-                {
-                    float const x0 = hx[0] / hw[0], x1 = hx[1] / hw[1], x2 = hx[2] / hw[2];
-                    float const y0 = hy[0] / hw[0], y1 = hy[1] / hw[1], y2 = hy[2] / hw[2];
-                    fx0 = fmaxf(fminf(fminf(x0, x1), x2) - margin, 0.0f);
-                    fx1 = fminf(fmaxf(fmaxf(x0, x1), x2) + margin, (float)W);
-                    fy0 = fmaxf(fminf(fminf(y0, y1), y2) - margin, 0.0f);
-                    fy1 = fminf(fmaxf(fmaxf(y0, y1), y2) + margin, (float)H);
+                    for (int i = 0; i < 3; i++)
+                    {
+                        int const j = (i + 1) % 3, k = (i + 2) % 3;
+                        float const A = fabsf(hy[j] * hw[k]) + fabsf(hy[k] * hw[j]);
+                        float const B = fabsf(hx[k] * hw[j]) + fabsf(hx[j] * hw[k]);
+                        float const Cc = fabsf(hx[j] * hy[k]) + fabsf(hx[k] * hy[j]);
+                        pushed[i] = r.c[i] + 0x1p-22f * ((A * ((float)W + 1.0f) + B * ((float)H + 1.0f)) + Cc);
+                    }
+                    float x[3], y[3];
+                    bool defined = true;
+#pragma unroll
+                    for (int v = 0; v < 3; v++)
+                    {
+                        // vertex v of T': where the pushed lines of the other two edges meet
+                        int const i = (v + 1) % 3, j = (v + 2) % 3;
+                        float const p0 = r.a[i] * r.b[j], p1 = r.a[j] * r.b[i];
+                        float const D = p0 - p1;
+                        x[v] = (r.b[i] * pushed[j] - r.b[j] * pushed[i]) / D;
+                        y[v] = (r.a[j] * pushed[i] - r.a[i] * pushed[j]) / D;
+                        // The three half-planes bound a triangle only if their normals turn the same way round (for the exact
+                        // coefficients D = det * w_v > 0); with coefficients that are themselves rounding noise they may
+                        // enclose an unbounded wedge instead, which no three corner points contain. NaN fails the test too.
+                        defined = defined && (D > 0x1p-21f * (fabsf(p0) + fabsf(p1))) && (x[v] == x[v]) && (y[v] == y[v]);
+                    }
+                    if (defined)
+                    {
+                        fx0 = fmaxf(fminf(fminf(x[0], x[1]), x[2]) - 1.0f, 0.0f);
+                        fx1 = fminf(fmaxf(fmaxf(x[0], x[1]), x[2]) + 1.0f, (float)W);
+                        fy0 = fmaxf(fminf(fminf(y[0], y[1]), y[2]) - 1.0f, 0.0f);
+                        fy1 = fminf(fmaxf(fmaxf(y[0], y[1]), y[2]) + 1.0f, (float)H);
+                    }
                 }
                 minX = (int)fx0;
                 minY = (int)fy0;
