@@ -782,6 +782,24 @@ def test_oetf_bit_exact(gpu, function, size):
     assert (got[H:] == untouched).all() and (got[:, W:] == untouched).all()
 
 
+@pytest.mark.parametrize("function", [0, 1])
+def test_oetf_every_code_value(gpu, function):
+    """All 65536 UNORM16 codes in every colour channel (the kernel goes through a 65536-entry table built on the device): the
+    whole transfer function, exhaustively, against the oracle's pow() evaluation."""
+    codes = np.arange(65536, dtype=np.uint16).reshape(256, 256)
+    img = np.stack([codes, codes[::-1, ::-1], codes.T, codes], -1).copy()
+    target = gpu.pl.SceneTexture(256, 256)
+    target.color[:256, :256] = torch.from_numpy(img.view(np.int16)).cuda()
+    gpu.pl.recordOETF(None, target, 256, 256, function)
+    torch.cuda.synchronize()
+    got = target.color_numpy()[:256, :256]
+    want = gpu.ob.oetf(img.copy(), function)
+    assert (got == want).all()
+    # monotone, fixes 0 and 1, alpha untouched
+    curve = got[..., 0].reshape(-1).astype(np.int64)
+    assert curve[0] == 0 and curve[-1] == 65535 and (np.diff(curve) >= 0).all() and (got[..., 3] == img[..., 3]).all()
+
+
 def test_oetf_known_values(gpu):
     img = np.zeros((1, 4, 4), np.uint16)
     img[0, :, 0] = [0, 65535, 32768, 100]
