@@ -2119,6 +2119,24 @@ int szg_default_mesh(int kind, szg_asset_mesh* out)
         std::vector<uint32_t> indices;
         szg_asset_surface surface{};
         szg_aabb bounds{};
+        // one surface over all indices with the default material; bounds = AABB::create(min, max) of the positions
+        void finish()
+        {
+            float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+            float hi[3] = {std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest()};
+            for (szg_vertex_packed const& v : vertices)
+            {
+                for (int k = 0; k < 3; k++)
+                {
+                    lo[k] = v.position[k] < lo[k] ? v.position[k] : lo[k];
+                    hi[k] = v.position[k] > hi[k] ? v.position[k] : hi[k];
+                }
+            }
+            szg_aabb_create(lo, hi, &bounds);
+            surface.first_index = 0;
+            surface.index_count = static_cast<uint32_t>(indices.size());
+            surface.material = -1;
+        }
     };
     static const Builtin builtins[2] = {
         [] {
@@ -2153,6 +2171,7 @@ int szg_default_mesh(int kind, szg_asset_mesh* out)
                     b.indices.push_back(start + i);
                 }
             }
+            b.finish();
             return b;
         }(),
         [] {
@@ -2172,30 +2191,9 @@ int szg_default_mesh(int kind, szg_asset_mesh* out)
                 b.vertices.push_back(v);
             }
             b.indices = {0, 1, 3, 1, 2, 3};
+            b.finish();
             return b;
         }()};
-    static const bool boundsDone = [] {
-        for (Builtin const& bc : builtins)
-        {
-            Builtin& b = const_cast<Builtin&>(bc);
-            float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
-            float hi[3] = {std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest()};
-            for (szg_vertex_packed const& v : b.vertices)
-            {
-                for (int k = 0; k < 3; k++)
-                {
-                    lo[k] = v.position[k] < lo[k] ? v.position[k] : lo[k];
-                    hi[k] = v.position[k] > hi[k] ? v.position[k] : hi[k];
-                }
-            }
-            szg_aabb_create(lo, hi, &b.bounds);
-            b.surface.first_index = 0;
-            b.surface.index_count = static_cast<uint32_t>(b.indices.size());
-            b.surface.material = -1;
-        }
-        return true;
-    }();
-    (void)boundsDone;
     Builtin const& b = builtins[kind];
     out->name = kind == SZG_DEFAULT_MESH_CUBE ? "mesh_Cube" : "mesh_Plane";
     out->vertices = b.vertices.data();
