@@ -370,9 +370,11 @@ int szg_skyview_record_multiscatter_lut(szg_skyview_t* p, void* stream, uint32_t
 int szg_skyview_multiscatter_lut(const szg_skyview_t* p, szg_image* out);
 
 /* Accessors to the LUT images the pipeline owns (skyview.hpp:52-97 `map`).
- * A caller that WRITES the transmittance texels itself (tests upload a LUT) must fetch the image through
- * szg_skyview_transmittance_lut for each such write: the call marks the LUT as externally written, and the next pass
- * that consumes it first re-scans the texels (the kernels keep a range flag of the LUT next to it). */
+ * A caller that WRITES the texels of either LUT itself (tests upload a LUT; the multi-GPU path all-gathers sky-view row
+ * slices into the image) must fetch the image through the accessor for each such write, or record the pass that produces
+ * the slices (szg_skyview_record_skyview_lut_rows) before it: either marks the LUT as externally written, and the next
+ * pass that consumes it first re-scans the texels (the kernels keep a status word next to each LUT: the transmittance
+ * LUT's value range, the sky-view LUT's finiteness). */
 int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out);
 int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out);
 

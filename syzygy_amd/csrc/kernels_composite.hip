@@ -27,6 +27,7 @@ struct SkyLut
 {
     const float4* texels;
     int width, height;
+    bool finite; // status dword behind the texels (szg_launch.hpp "sky-view LUT block"): every texel a finite, moderate number
 };
 
 // sampleMap_Direction, camera.comp:70-121 (sky-view LUT: LINEAR, CLAMP_TO_EDGE,
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
 
     Atm const a = load_atm(atmospheres + atmosphereIndex);
     TLut const L = make_tlut(tlut, tW, tH);
-    SkyLut const S{slut, sW, sH};
+    SkyLut const S{slut, sW, sH, reinterpret_cast<const unsigned*>(slut + (size_t)sW * (size_t)sH)[0] == 0u};
     const szg_camera_packed* cam = cameras + cameraIndex;
 
     // camera.comp:315-316 (nearest at the pixel's own texel)
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
         // Both horizon angles asin(Rp / r) must exist: the camera's (every texel of the sky-view LUT depends on it) and the
         // surface's (where the LUT is sampled from); same expressions as skyview_LUT.comp:106-112 and camera.comp:75-77.
         bool const aboveGround = (a.planetRadius / length(position)) <= 1.0f && fractionOfSunVisible <= 1.0f;
-        bool const environmentFinite = a.extModerate && a.sunSane && L.moderate && normalFinite && aboveGround &&
+        bool const environmentFinite = a.extModerate && a.sunSane && L.moderate && S.finite && normalFinite && aboveGround &&
                                        inRange(cameraR2, a.extFloor2, a.extCeil2) && inRange(surfaceR2, a.extFloor2, a.extCeil2);
         if (m.metallic != 0.0f || !environmentFinite)
         {

@@ -196,6 +196,29 @@ __global__ __launch_bounds__(256, 4) void k_skyview(const szg_atmosphere_packed*
     float const distance = raycastAtmosphere(a, origin, direction);
     V3 const luminance = scatteringIntegral(L, a, origin, direction, distance);
     lut[y * W + x] = make_float4(luminance.x, luminance.y, luminance.z, 1.0f);
+    // status dword behind the texels (szg_launch.hpp "sky-view LUT block"): bit 0 = some texel is not a finite number of
+    // moderate size. Ordinary LUTs never set it; the composite reads it before it skips a sample of this LUT unseen.
+    if (!slutTexelFinite(luminance.x, luminance.y, luminance.z))
+    {
+        atomicOr(reinterpret_cast<unsigned*>(lut + (size_t)W * (size_t)H), 1u);
+    }
+}
+
+// Status dword of a sky-view LUT whose texels were (partly) written by someone else: row slices gathered from other ranks,
+// or an upload through szg_skyview_skyview_lut().
+__global__ __launch_bounds__(256) void k_slut_check(float4* __restrict__ lut, unsigned n)
+{
+    unsigned const id = blockIdx.x * 256u + threadIdx.x;
+    bool ok = true;
+    if (id < n)
+    {
+        float4 const t = lut[id];
+        ok = slutTexelFinite(t.x, t.y, t.z);
+    }
+    if (!waveAll(ok) && (threadIdx.x & 63u) == 0u)
+    {
+        atomicOr(reinterpret_cast<unsigned*>(lut + n), 1u);
+    }
 }
 
 // Aerial-perspective froxel LUT (include/szg/abi.h "Aerial-perspective froxel LUT"): one froxel per lane, the
@@ -361,6 +384,18 @@ hipError_t launch_lut_range(hipStream_t s, float* lut, unsigned W, unsigned H)
     return hipGetLastError();
 }
 
+hipError_t launch_slut_check(hipStream_t s, float* lut, unsigned W, unsigned H)
+{
+    unsigned const n = W * H;
+    hipError_t const e = hipMemsetAsync(lut + (size_t)n * 4u, 0, 4, s);
+    if (e != hipSuccess)
+    {
+        return e;
+    }
+    hipLaunchKernelGGL(k_slut_check, dim3((n + 255u) / 256u), dim3(256), 0, s, reinterpret_cast<float4*>(lut), n);
+    return hipGetLastError();
+}
+
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
                           unsigned rowBegin, unsigned rowEnd)
@@ -372,6 +407,15 @@ hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
     if (rowBegin >= rowEnd || W == 0u)
     {
         return hipSuccess;
+    }
+    if (rowBegin == 0u && rowEnd == H)
+    {
+        // a whole LUT: its status dword starts clear and the kernel sets it (partial launches leave it to launch_slut_check)
+        hipError_t const e = hipMemsetAsync(lut + (size_t)W * H * 4u, 0, 4, s);
+        if (e != hipSuccess)
+        {
+            return e;
+        }
     }
     dim3 const grid((W + 31u) / 32u, (rowEnd - rowBegin + 7u) / 8u);
     hipLaunchKernelGGL(k_skyview, grid, dim3(256), 0, s, d_atm, atmIndex, d_cam, camIndex, reinterpret_cast<const float4*>(tlut),

@@ -257,6 +257,9 @@ struct szg_skyview
     // false while the caller may have written the transmittance texels through szg_skyview_transmittance_lut():
     // the next consumer recomputes the block's status dword first (szg_launch.hpp "transmittance LUT block")
     mutable bool tlutStatusValid = false;
+    // the same for the sky-view LUT's status dword (szg_launch.hpp "sky-view LUT block"): false after a partial (row-slice)
+    // launch or after szg_skyview_skyview_lut() handed the texels out
+    mutable bool slutStatusValid = false;
 };
 
 static hipError_t ensure_tlut_status(szg_skyview* p, hipStream_t s)
@@ -267,6 +270,17 @@ static hipError_t ensure_tlut_status(szg_skyview* p, hipStream_t s)
     }
     hipError_t const e = szg::launch_lut_range(s, p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height);
     p->tlutStatusValid = (e == hipSuccess);
+    return e;
+}
+
+static hipError_t ensure_slut_status(szg_skyview* p, hipStream_t s)
+{
+    if (p->slutStatusValid)
+    {
+        return hipSuccess;
+    }
+    hipError_t const e = szg::launch_slut_check(s, p->d_skyview, p->desc.skyview_width, p->desc.skyview_height);
+    p->slutStatusValid = (e == hipSuccess);
     return e;
 }
 
@@ -379,7 +393,7 @@ int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int de
                              szg::tlut_block_bytes(d.transmittance_width, d.transmittance_height));
     if (e == hipSuccess)
     {
-        e = hipMalloc(reinterpret_cast<void**>(&p->d_skyview), (size_t)d.skyview_width * d.skyview_height * 16u);
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_skyview), szg::slut_block_bytes(d.skyview_width, d.skyview_height));
     }
     size_t const aerialBytes = (size_t)SZG_AERIAL_W * SZG_AERIAL_H * SZG_AERIAL_D * 16u;
     if (e == hipSuccess)
@@ -451,6 +465,7 @@ int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out)
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_skyview_lut: NULL argument");
     }
     *out = make_image(p->d_skyview, p->desc.skyview_width, p->desc.skyview_height, SZG_FORMAT_RGBA32_SFLOAT);
+    p->slutStatusValid = false; // the caller may write the texels through this view (row slices gathered from other ranks)
     return SZG_OK;
 }
 
@@ -486,6 +501,8 @@ int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t
                                 p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
                                 p->desc.skyview_width, p->desc.skyview_height, row_begin, row_end));
     p->haveSkyview = true;
+    // a launch over all rows leaves the status dword behind the texels right; a slice does not know the other rows
+    p->slutStatusValid = (row_begin == 0u && row_end == p->desc.skyview_height);
     return SZG_OK;
 }
 
@@ -550,6 +567,7 @@ static int record_composite(szg_skyview_t* p, void* stream, const szg_scene_text
         aerial.maxDistance = p->aerialMaxDistance;
     }
     SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
+    SZG_HIP(ensure_slut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(szg::launch_composite(static_cast<hipStream_t>(stream), *scene_texture, draw_rect.width, draw_rect.height, t, *gbuffer,
                                   sun, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, d_lights, sun_light_index,
                                   p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,

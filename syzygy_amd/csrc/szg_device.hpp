@@ -151,6 +151,8 @@ SZG_DEV float xorSign(float x, unsigned signMask)
 {
     return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) ^ signMask);
 }
+// a sky-view LUT texel the composite may leave unsampled: a finite number well inside the fp32 range
+SZG_DEV bool slutTexelFinite(float r, float g, float b) { return fabsf(r) <= 0x1p100f && fabsf(g) <= 0x1p100f && fabsf(b) <= 0x1p100f; }
 SZG_DEV bool inRange(float x, float lo, float hi) { return x >= lo && x <= hi; } // false for NaN
 SZG_DEV float divN0(float a, float b) { return divR0(a, b, rcpN(b)); }
 // true when `c` holds on every active lane: one compare into a lane mask and one scalar test (HIP's __all() builds two

@@ -56,6 +56,13 @@ inline size_t tlut_block_bytes(unsigned W, unsigned H) { return (size_t)W * H * 
 hipError_t launch_lut_range(hipStream_t s, float* lut, unsigned W, unsigned H);
 hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, float* lut, unsigned W,
                                 unsigned H);
+// Sky-view LUT block: W*H RGBA32F texels followed by ONE status dword (16 bytes reserved): 0 when every texel's rgb is a
+// finite number of moderate size (|x| <= 2^100). The composite consults it before it leaves a sample of this LUT unevaluated
+// (the reflection term of a non-metal pixel is an exact zero only if the sample is finite). launch_skyview over all rows
+// maintains it; after a partial launch (row slices of the multi-GPU path, completed by an all-gather) or a write by the
+// caller, launch_slut_check recomputes it from the texels.
+inline size_t slut_block_bytes(unsigned W, unsigned H) { return (size_t)W * H * 16u + 16u; }
+hipError_t launch_slut_check(hipStream_t s, float* lut, unsigned W, unsigned H);
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
                           unsigned rowBegin, unsigned rowEnd);

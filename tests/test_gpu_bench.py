@@ -68,9 +68,17 @@ def test_example_render_gltf_runs(tmp_path):
                                              ("random_sweep_frames.py", 230, 250), ("random_sweep_params_fuzz.py", 1000, 1060),
                                              ("random_sweep_params_fuzz.py", 1500, 1530), ("random_sweep_raster_fuzz.py", 100, 130),
                                              ("random_sweep_raster_fuzz.py", 1375, 1390), ("random_sweep_raster_fuzz.py", 2920, 2935)])
-def test_random_sweep_tools_find_nothing(tool, first, last):
+def test_random_sweep_tools_find_nothing(tool, first, last, extra=()):
     """tools/random_sweep_*.py are how the round's rare parity bugs were found; a slice of each — the seed
     ranges that once held mismatches — runs here so that the tools keep working and those cases stay fixed."""
-    r = subprocess.run([sys.executable, os.path.join("tools", tool), str(first), str(last)], cwd=ROOT, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, os.path.join("tools", tool), str(first), str(last), *extra], cwd=ROOT, capture_output=True, text=True,
+                       timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "mismatching seeds: 0" in r.stdout, r.stdout[-2000:]
+
+
+def test_random_sweep_with_degenerate_lut_extents():
+    """LUTs of 2 ... 7 texels a side: their marches produce NaN texels in perfectly sane atmospheres, which only the sky-view
+    LUT's status word (not any inference from the parameters) can tell the composite (seeds 1721, 1884 mismatched before it)."""
+    test_random_sweep_tools_find_nothing("random_sweep_frames.py", 1715, 1725, ("tiny",))
+    test_random_sweep_tools_find_nothing("random_sweep_frames.py", 1880, 1890, ("tiny",))

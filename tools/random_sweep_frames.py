@@ -1,6 +1,7 @@
 """Random parity sweep on the GPU box: frames with random extents, LUT sizes, cameras, sun elevations, atmosphere edits,
 spot-light parameters, shadow maps and row tiles, GPU vs oracle bit for bit (NaN patterns included).
-usage: python tools/random_sweep_frames.py FIRST_SEED LAST_SEED   (400 seeds take ~15 s)"""
+usage: python tools/random_sweep_frames.py FIRST_SEED LAST_SEED [tiny]   (400 seeds take ~15 s; "tiny": degenerate LUT extents,
+2 ... 7 texels a side, whose marches do produce NaN texels in sane atmospheres)"""
 import sys, numpy as np, torch, ctypes as C
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from tests import util
@@ -14,6 +15,8 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     rng=np.random.default_rng(seed)
     W=int(rng.integers(17,150)); H=int(rng.integers(9,90))
     tl=(int(rng.integers(8,200)), int(rng.integers(4,60))); sl=(int(rng.integers(8,200)), int(rng.integers(4,100)))
+    if len(sys.argv)>3 and sys.argv[3]=='tiny':
+        tl=(int(rng.choice([2,3,5,7,640])), int(rng.choice([2,3,4,130]))); sl=(int(rng.choice([2,3,5,300])), int(rng.choice([2,3,4,9])))
     nsp=int(rng.integers(0,12))
     cam=scene.default_camera()
     cam.cameraPosition[:]=[float(rng.uniform(-40,40)), float(-10.0**rng.uniform(-1.0,4.0)), float(rng.uniform(-50,30))]
