@@ -59,9 +59,6 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
         poison(rng, inp.spots[int(rng.integers(0, nsp))], int(rng.integers(1, 4)))
     else:
         poison(rng, inp.atm, 2)
-    sun = inp.atm.incidentDirectionSun
-    if not (sun[0] * sun[0] + sun[2] * sun[2] >= 1.0e-12 or np.isnan(sun[0] + sun[2])):
-        continue  # an exactly vertical sun has no azimuth: normalize(vec2(0, 0)), undefined in the reference too
     dirs = (abi.DirectionalLightPacked * 2)(inp.sun, inp.moon)
     cameras = pl.TStagedBuffer(abi.CameraPacked, 1)
     cameras.push(inp.cam)
