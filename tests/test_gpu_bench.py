@@ -82,3 +82,8 @@ def test_random_sweep_with_degenerate_lut_extents():
     LUT's status word (not any inference from the parameters) can tell the composite (seeds 1721, 1884 mismatched before it)."""
     test_random_sweep_tools_find_nothing("random_sweep_frames.py", 1715, 1725, ("tiny",))
     test_random_sweep_tools_find_nothing("random_sweep_frames.py", 1880, 1890, ("tiny",))
+
+
+def test_random_sweep_of_the_extension_luts():
+    """The opt-in multi-scattering and aerial-perspective LUTs against their scalar oracles under hostile parameter blocks."""
+    test_random_sweep_tools_find_nothing("random_sweep_params_fuzz.py", 0, 40, ("extensions",))

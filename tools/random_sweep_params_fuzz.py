@@ -3,7 +3,7 @@ spot-light blocks are overwritten with NaN, +-inf, zeros, negative, denormal, hu
 patterns (planet radius 0, atmosphere inside the planet, zero or NaN sun direction, singular matrices, zero falloff...).
 Every pass on the GPU vs the oracle on the same blocks: both LUTs, the lights pass and the final frame bit-identical including
 the NaN pattern. Exercises the generic (non-lean) paths and every guard of the exact shortcuts.
-usage: python tools/random_sweep_params_fuzz.py FIRST_SEED LAST_SEED"""
+usage: python tools/random_sweep_params_fuzz.py FIRST_SEED LAST_SEED [extensions]   ("extensions": the opt-in LUTs too)"""
 import ctypes as C
 import os
 import sys
@@ -104,6 +104,17 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
 
     report = {"transmittance": differ(got_t, tlut), "skyview": differ(got_s, slut), "lights": differ(got_lights, want_lights),
               "frame": differ(got, fr.debug), "rgba16": int((got_q != fr.color).sum())}
+    if len(sys.argv) > 3 and sys.argv[3] == "extensions":
+        # the opt-in LUTs without a reference counterpart (multi-scattering, aerial perspective) against their scalar oracles
+        max_distance = float(10.0 ** rng.uniform(-3, 0))
+        sky.recordMultiScatterLUT(None, 0, atmospheres)
+        sky.recordAerialLUT(None, 0, atmospheres, 0, cameras, max_distance)
+        torch.cuda.synchronize()
+        lum_im, tr_im = sky.aerialLUT()
+        want_ms, _ = ob.multiscatter_lut(inp.atm, tlut)
+        want_lum, want_tr = ob.aerial_lut(inp.atm, inp.cam, tlut, max_distance, threads=8)
+        report.update({"multiscatter": differ(sky.download_lut(sky.multiScatterLUT()), want_ms),
+                       "aerial luminance": differ(sky.download_lut(lum_im), want_lum), "aerial transmittance": differ(sky.download_lut(tr_im), want_tr)})
     if any(report.values()):
         bad += 1
         print("seed", seed, "MISMATCH", report, "W,H", W, H, "luts", tl, sl, "spots", nsp, "skip", skip, "poisoned", "atm" if which < 0.5 else
