@@ -250,13 +250,20 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
 
         // computeGeometryLuminanceTransfer, camera.comp:237-278
         V3 const surfacePosition = m.position;
-        V3 const transmittanceToSurface = sampleT_Segment(L, a, position, surfacePosition);
+        // the two transmittance samples of this branch with the lean exact operators when the whole wave allows it
+        V3 const toSurface = surfacePosition - position;
+        bool const samplesLean = waveAll(a.lean && leanRadius2(a, dot(position, position)) && leanRadius2(a, dot(surfacePosition, surfacePosition)) &&
+                                         leanLength2(dot(toSurface, toSurface)) &&
+                                         leanLength2(dot(a.incidentDirectionSun, a.incidentDirectionSun)));
+        V3 const transmittanceToSurface = samplesLean ? sampleT_Segment<true>(L, a, position, surfacePosition)
+                                                      : sampleT_Segment<false>(L, a, position, surfacePosition);
         V3 const lightDirection = normalize(-a.incidentDirectionSun);
         V3 const viewDirection = normalize(-direction);
         float pt0 = 0.0f, pt1 = 0.0f;
         bool const shadowedByPlanet = raySphere(surfacePosition, lightDirection, a.planetRadius, pt0, pt1) && pt0 > 0.0f;
         V3 const brdf = brdfMix(m, lightDirection, viewDirection);
-        V3 const transmittanceToSun = sampleT_Ray(L, a, surfacePosition, lightDirection);
+        V3 const transmittanceToSun = samplesLean ? sampleT_Ray<true>(L, a, surfacePosition, lightDirection)
+                                                  : sampleT_Ray<false>(L, a, surfacePosition, lightDirection);
         float const fractionOfSunVisible = a.planetRadius / length(m.position); // camera.comp:144-147
         float const scalar = (shadowFactor * fractionOfSunVisible) * (shadowedByPlanet ? 0.0f : 1.0f);
         base = ((((scalar * transmittanceToSun) * transmittanceToSurface) * m.occlusion) * brdf) *

@@ -289,7 +289,7 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
 //
 // A spot light contributes exactly 0 when distance(st, 0.5) / 0.5 >= 1 (lights.comp:84-88). |s - 0.5| > 0.505 on
 // either axis implies that with a 1 % margin, far above any rounding of the exact evaluation, so rejecting there
-// never changes a result. cw == 0 (st = inf/NaN) is not rejected.
+// never changes a result — unless the other axis is NaN. cw == 0 (st = inf/NaN) is not rejected.
 
 // Runtime (wave-uniform) selection between the lean exact ops of szg_device.hpp and the generic operators;
 // both give the IEEE correctly rounded result, the lean ones only inside their operand ranges.
@@ -403,7 +403,10 @@ SZG_DEV bool surelyOutsideCone(const LightCull& c, V3 p)
     float const acw = fabsf(cw);
     float const ax = fabsf(cx - 0.5f * cw);
     float const ay = fabsf(cy - 0.5f * cw);
-    return acw > 0.0f && (ax > 0.505f * acw || ay > 0.505f * acw);
+    // one axis outside implies q = dx^2 + dy^2 >= 0.25 only if the other axis is a number: with a NaN there (inf - inf in a
+    // projection with entries near FLT_MAX) q is NaN, the exact test q >= 0.25 fails and the light contributes in full
+    float const both = ax + ay;
+    return acw > 0.0f && both == both && (ax > 0.505f * acw || ay > 0.505f * acw);
 }
 
 __global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug, GBufferPtrs g, unsigned drawW,

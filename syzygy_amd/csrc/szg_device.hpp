@@ -643,15 +643,28 @@ template <bool LEAN = false> SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, 
 }
 
 // common.glinl:40-66 + :138-143 : sample at (radius, mu)
-SZG_DEV V3 sampleT_RadiusMu(const TLut& L, const Atm& a, float radius, float mu)
+template <bool LEAN = false> SZG_DEV V3 sampleT_RadiusMu(const TLut& L, const Atm& a, float radius, float mu)
 {
-    RadiusPart const p = radiusPart<false>(L, a, radius);
-    return sampleT_at<false>(L, a, p, mu);
+    RadiusPart const p = radiusPart<LEAN>(L, a, radius);
+    return sampleT_at<LEAN>(L, a, p, mu);
 }
 
+// Wave-uniform precondition of the LEAN forms of the samplers below, given the squared radii / lengths they take square roots
+// and quotients of: the atmosphere admits the lean ops (Atm::lean), every radius is above the lean floor and every
+// length a normal number of moderate size.
+SZG_DEV bool leanLength2(float x) { return inRange(x, 0x1p-60f, 0x1p60f); }
+SZG_DEV bool leanRadius2(const Atm& a, float r2) { return r2 >= a.leanFloor2 && r2 <= 0x1p60f; }
+
 // common.glinl:104-112
-SZG_DEV V3 sampleT_Ray(const TLut& L, const Atm& a, V3 position, V3 direction)
+template <bool LEAN = false> SZG_DEV V3 sampleT_Ray(const TLut& L, const Atm& a, V3 position, V3 direction)
 {
+    if (LEAN)
+    {
+        // length() = sqrt(dot) and the quotient, with the lean exact operators (same values)
+        float const radius = sqrtP(dot(position, position));
+        float const mu = divN0(dot(position, direction), radius * sqrtP(dot(direction, direction)));
+        return sampleT_RadiusMu<true>(L, a, radius, mu);
+    }
     float const radius = length(position);
     float const mu = dot(position, direction) / (length(position) * length(direction));
     return sampleT_RadiusMu(L, a, radius, mu);
@@ -682,8 +695,18 @@ SZG_DEV V3 segmentRatio(const TLut& L, const Atm& a, const RadiusPart& pFrom, fl
     V3 const q = flip ? (Tt / Tf) : (Tf / Tt);
     return clamp01(q);
 }
-SZG_DEV V3 sampleT_Segment(const TLut& L, const Atm& a, V3 from, V3 to)
+template <bool LEAN = false> SZG_DEV V3 sampleT_Segment(const TLut& L, const Atm& a, V3 from, V3 to)
 {
+    if (LEAN)
+    {
+        V3 const segment = to - from;
+        V3 const direction = segment * divN0(1.0f, sqrtP(dot(segment, segment))); // normalize()
+        float const lenFrom = sqrtP(dot(from, from));
+        float const lenTo = sqrtP(dot(to, to));
+        RadiusPart const pf = radiusPart<true>(L, a, lenFrom);
+        RadiusPart const pt = radiusPart<true>(L, a, lenTo);
+        return segmentRatio<true>(L, a, pf, dot(from, direction), lenFrom, pt, dot(to, direction), lenTo, sqrtP(dot(direction, direction)));
+    }
     V3 const direction = normalize(to - from);
     float const lenFrom = length(from);
     float const lenTo = length(to);
@@ -827,11 +850,28 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
 {
     MarchSetup m;
     m.origin = origin;
-    m.scatteringDir = -normalize(direction);
-    float const radius = length(origin);
-    float const mu = dot(origin, direction) / (length(origin) * length(direction));
+    // The per-ray setup with the lean exact operators (same values) when the whole wave's origins lie above the lean floor
+    // and the direction and sun vectors have ordinary lengths; otherwise hipcc's generic sqrtf / division.
+    float const origin2 = dot(origin, origin), direction2 = dot(direction, direction);
+    float const sun2 = dot(a.incidentDirectionSun, a.incidentDirectionSun);
+    bool const setupLean = waveAll(a.lean && leanRadius2(a, origin2) && leanLength2(direction2) && leanLength2(sun2));
+    float radius, mu, mu_sun;
     V3 const toSun = -a.incidentDirectionSun;
-    float const mu_sun = dot(origin, toSun) / (length(origin) * length(a.incidentDirectionSun));
+    if (setupLean)
+    {
+        float const lenDirection = sqrtP(direction2);
+        m.scatteringDir = -(direction * divN0(1.0f, lenDirection));
+        radius = sqrtP(origin2);
+        mu = divN0(dot(origin, direction), radius * lenDirection);
+        mu_sun = divN0(dot(origin, toSun), radius * sqrtP(sun2));
+    }
+    else
+    {
+        m.scatteringDir = -normalize(direction);
+        radius = length(origin);
+        mu = dot(origin, direction) / (length(origin) * length(direction));
+        mu_sun = dot(origin, toSun) / (length(origin) * length(a.incidentDirectionSun));
+    }
 
     float const incidentCosine = dot(a.incidentDirectionSun, m.scatteringDir);
     m.pR = phaseRayleigh(incidentCosine);
@@ -846,7 +886,7 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     m.r2 = radius * radius;
     m.r_musun = radius * mu_sun;
     m.up = mu > 0.0f;
-    m.T_origin = sampleT_RadiusMu(L, a, radius, m.up ? mu : -mu);
+    m.T_origin = setupLean ? sampleT_RadiusMu<true>(L, a, radius, m.up ? mu : -mu) : sampleT_RadiusMu<false>(L, a, radius, m.up ? mu : -mu);
     m.dS = sampleDistance / 32.0f;
 
     // leanRay: every radius met along the path stays >= 0.9 Rp and of moderate magnitude, the path length is
