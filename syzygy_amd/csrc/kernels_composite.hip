@@ -257,18 +257,23 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
                                          leanLength2(dot(a.incidentDirectionSun, a.incidentDirectionSun)));
         V3 const transmittanceToSurface = samplesLean ? sampleT_Segment<true>(L, a, position, surfacePosition)
                                                       : sampleT_Segment<false>(L, a, position, surfacePosition);
-        V3 const lightDirection = normalize(-a.incidentDirectionSun);
-        V3 const viewDirection = normalize(-direction);
+        // (normalize(), length() and the quotients below likewise: v * (1 / sqrt(dot)) and sqrt(dot) with the lean operators)
+        V3 const minusSun = -a.incidentDirectionSun, minusDirection = -direction;
+        float const direction2 = dot(minusDirection, minusDirection);
+        bool const vectorsLean = samplesLean && waveAll(leanLength2(direction2));
+        V3 const lightDirection = vectorsLean ? minusSun * divN0(1.0f, sqrtP(dot(minusSun, minusSun))) : normalize(minusSun);
+        V3 const viewDirection = vectorsLean ? minusDirection * divN0(1.0f, sqrtP(direction2)) : normalize(minusDirection);
         float pt0 = 0.0f, pt1 = 0.0f;
         bool const shadowedByPlanet = raySphere(surfacePosition, lightDirection, a.planetRadius, pt0, pt1) && pt0 > 0.0f;
         V3 const brdf = brdfMix(m, lightDirection, viewDirection);
         V3 const transmittanceToSun = samplesLean ? sampleT_Ray<true>(L, a, surfacePosition, lightDirection)
                                                   : sampleT_Ray<false>(L, a, surfacePosition, lightDirection);
-        float const fractionOfSunVisible = a.planetRadius / length(m.position); // camera.comp:144-147
+        float const fractionOfSunVisible = vectorsLean ? divN0(a.planetRadius, sqrtP(dot(m.position, m.position)))
+                                                       : a.planetRadius / length(m.position); // camera.comp:144-147
         float const scalar = (shadowFactor * fractionOfSunVisible) * (shadowedByPlanet ? 0.0f : 1.0f);
         base = ((((scalar * transmittanceToSun) * transmittanceToSurface) * m.occlusion) * brdf) *
                clampf(dot(m.normal, lightDirection), 0.0f, 1.0f);
-        l0 = length(surfacePosition - position);
+        l0 = vectorsLean ? sqrtP(dot(toSurface, toSurface)) : length(surfacePosition - position);
         if (FAST)
         {
             // APPROXIMATE extension (abi.h): aerial perspective from the froxel LUT instead of the inline march
@@ -292,7 +297,8 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
         bool const normalFinite = fabsf(m.normal.x) <= nBig && fabsf(m.normal.y) <= nBig && fabsf(m.normal.z) <= nBig;
         // Both horizon angles asin(Rp / r) must exist: the camera's (every texel of the sky-view LUT depends on it) and the
         // surface's (where the LUT is sampled from); same expressions as skyview_LUT.comp:106-112 and camera.comp:75-77.
-        bool const aboveGround = (a.planetRadius / length(position)) <= 1.0f && fractionOfSunVisible <= 1.0f;
+        float const cameraSinHorizon = vectorsLean ? divN0(a.planetRadius, sqrtP(cameraR2)) : a.planetRadius / length(position);
+        bool const aboveGround = cameraSinHorizon <= 1.0f && fractionOfSunVisible <= 1.0f;
         bool const environmentFinite = a.extModerate && a.sunSane && L.moderate && S.finite && normalFinite && aboveGround &&
                                        inRange(cameraR2, a.extFloor2, a.extCeil2) && inRange(surfaceR2, a.extFloor2, a.extCeil2);
         if (m.metallic != 0.0f || !environmentFinite)
