@@ -265,7 +265,9 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
         V3 const viewDirection = vectorsLean ? minusDirection * divN0(1.0f, sqrtP(direction2)) : normalize(minusDirection);
         float pt0 = 0.0f, pt1 = 0.0f;
         bool const shadowedByPlanet = raySphere(surfacePosition, lightDirection, a.planetRadius, pt0, pt1) && pt0 > 0.0f;
-        V3 const brdf = brdfMix(m, lightDirection, viewDirection);
+        V3 const halfSum = lightDirection + viewDirection;
+        bool const brdfLean = vectorsLean && waveAll(inRange(dot(halfSum, halfSum), 0x1p-40f, 8.0f));
+        V3 const brdf = brdfLean ? brdfMix<true>(m, lightDirection, viewDirection) : brdfMix<false>(m, lightDirection, viewDirection);
         V3 const transmittanceToSun = samplesLean ? sampleT_Ray<true>(L, a, surfacePosition, lightDirection)
                                                   : sampleT_Ray<false>(L, a, surfacePosition, lightDirection);
         float const fractionOfSunVisible = vectorsLean ? divN0(a.planetRadius, sqrtP(dot(m.position, m.position)))
