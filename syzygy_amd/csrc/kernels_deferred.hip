@@ -265,10 +265,18 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
         // colour * strength is the numerator of lean divisions (an infinite one would come out NaN instead of inf) and a
         // factor of the culled term: a spot light's term for a pixel outside its cone is (colour * strength / falloff) * 0 *
         // brdf, an exact zero only if every factor is finite. The light's own factors are checked here, the pixel's in k_lights.
-        bool const finite = fabsf(r.colorStrength[0]) <= hi && fabsf(r.colorStrength[1]) <= hi && fabsf(r.colorStrength[2]) <= hi &&
+        auto numerator = [&](float a) { return a == 0.0f || (fabsf(a) >= lo && fabsf(a) <= hi); };
+        // rows of the shadow matrix: with |position| <= 2^30 (checked per pixel) entries up to 2^28 keep every projected
+        // coordinate — the numerators of the lean divisions by w — below 2^60
+        bool rowsModerate = true;
+        for (int k = 0; k < 16; k++)
+        {
+            rowsModerate = rowsModerate && fabsf(r.shadowRows[k]) <= 0x1p28f;
+        }
+        bool const finite = numerator(r.colorStrength[0]) && numerator(r.colorStrength[1]) && numerator(r.colorStrength[2]) &&
                             fabsf(r.position[0]) <= hi && fabsf(r.position[1]) <= hi && fabsf(r.position[2]) <= hi &&
                             fabsf(r.dir[0]) <= 2.0f && fabsf(r.dir[1]) <= 2.0f && fabsf(r.dir[2]) <= 2.0f;
-        r.leanOK = (r.isSpot != 0u && finite && inRange(r.falloffDistance, lo, hi) && inRange(r.falloffFactor, lo, hi)) ? 1u : 0u;
+        r.leanOK = (r.isSpot != 0u && finite && rowsModerate && inRange(r.falloffDistance, lo, hi) && inRange(r.falloffFactor, lo, hi)) ? 1u : 0u;
         r.pad[0] = r.leanOK; // "cullable"
     }
     r.pad[1] = 0u;
@@ -294,6 +302,9 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
 // Runtime (wave-uniform) selection between the lean exact ops of szg_device.hpp and the generic operators;
 // both give the IEEE correctly rounded result, the lean ones only inside their operand ranges.
 SZG_DEV float divU(bool lean, float a, float b, float y) { return lean ? divR(a, b, y) : a / b; }
+// numerator of a lean division: 0, or not tiny (the residual of the one-correction division underflows below ~2^-100; its
+// upper bound comes from the light's rows, checked once in k_light_prep)
+SZG_DEV bool leanNumerator(float a) { return a == 0.0f || fabsf(a) >= 0x1p-60f; }
 SZG_DEV float sqrtU(bool lean, float x) { return lean ? sqrtN(x) : sqrtf(x); }
 
 // One light's term of the sum (lights.comp:141-161), exact.
@@ -314,8 +325,11 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     // (=> lightFalloff = factor * (dist / falloffDistance)^2 with the per-light constants checked by k_light_prep),
     // the half-vector length, and the position magnitude. One lane outside sends the wave down the generic path.
     float const lo = 0x1p-30f, hi = 0x1p30f;
+    // (numerators too: the one-correction division returns NaN for an infinite numerator where the quotient is inf — a
+    // projection with entries near FLT_MAX — and is not verified for denormal ones)
+    float const cz = (L.map != nullptr) ? R[8] * m.position.x + R[9] * m.position.y + R[10] * m.position.z + R[11] * 1.0f : 0.0f;
     bool const lean = waveAll(L.leanOK != 0u && positionModerate && inRange(fabsf(cw), lo, hi) && inRange(d2, lo, hi) &&
-                            inRange(hd, 0x1p-40f, 8.0f));
+                            inRange(hd, 0x1p-40f, 8.0f) && leanNumerator(cx) && leanNumerator(cy) && leanNumerator(cz));
 
     float const ycw = lean ? rcpN(cw) : 0.0f;
     float const sx = divU(lean, cx, cw, ycw);
@@ -342,7 +356,6 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     float shadow = 1.0f;
     if (L.map != nullptr)
     {
-        float const cz = R[8] * m.position.x + R[9] * m.position.y + R[10] * m.position.z + R[11] * 1.0f;
         float const sz = divU(lean, cz, cw, ycw);
         // projectedNormal = shadowMatrix * vec4(normal, 0)
         float const nx = R[0] * m.normal.x + R[1] * m.normal.y + R[2] * m.normal.z + R[3] * 0.0f;
