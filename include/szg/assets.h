@@ -23,10 +23,10 @@
  * the two image encodings glTF 2.0 allows, decoded as stb_image does for a 4-channel request:
  *   PNG   bit depths 1-16, all colour types, tRNS, Adam7; 16-bit samples keep their high byte; gamma chunks ignored;
  *         checksums not verified
- *   JPEG  baseline / extended-sequential / progressive Huffman, 8 bit, grey or three components with any sampling
- *         factors, restart intervals, interleaved or per-component scans; stb_image's integer inverse DCT,
+ *   JPEG  baseline / extended-sequential / progressive Huffman, 8 bit, grey, three components or four (Adobe CMYK /
+ *         YCCK) with any sampling factors, restart intervals, interleaved or per-component scans; stb_image's integer inverse DCT,
  *         triangle-filter chroma upsampling and fixed-point YCbCr conversion (syzygy_amd/csrc/host_jpeg.cpp).
- *         Arithmetic-coded, lossless, 12-bit and CMYK files are NOT decoded.
+ *         Arithmetic-coded, lossless and 12-bit files are NOT decoded.
  * An image that is not decoded fails like any undecodable image does in the reference (warning, default map kept).
  * The reference holds no usable asset for this path (assets/sphere.glb is a 132-byte LFS pointer): parity unpinned;
  * tests write glTF/GLB/PNG/JPEG files with independent Python encoders and compare array by array (JPEG: against a

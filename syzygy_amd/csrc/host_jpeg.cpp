@@ -9,7 +9,8 @@
 // restatement of the same arithmetic and against the source picture within JPEG's own error.
 // Progressive files (SOF2: spectral selection and successive approximation, T.81 annex G) accumulate their coefficients
 // over the scans and are dequantised and transformed at the end, as stb_image does.
-// Not decoded: arithmetic coding, lossless / hierarchical, 12-bit, CMYK / YCCK — such files fail like any undecodable image.
+// Four-component Adobe files (CMYK, YCCK) are mapped to RGB the way stb_image does.
+// Not decoded: arithmetic coding, lossless / hierarchical, 12-bit — such files fail like any undecodable image.
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -376,9 +377,9 @@ class Decoder
             why = "JPEG with a zero dimension";
             return false;
         }
-        if ((n != 1 && n != 3) || len != 6 + 3 * n)
+        if ((n != 1 && n != 3 && n != 4) || len != 6 + 3 * n)
         {
-            why = n == 4 ? "CMYK / YCCK JPEG is not decoded by this build" : "bad SOF component count";
+            why = "bad SOF component count";
             return false;
         }
         if (static_cast<uint64_t>(width_) * static_cast<uint64_t>(height_) > (1ull << 28))
@@ -1142,6 +1143,45 @@ class Decoder
                 for (int i = 0; i < width_; i++)
                 {
                     out[i * 4] = out[i * 4 + 1] = out[i * 4 + 2] = rows[0][i];
+                }
+            }
+            else if (n == 4)
+            {
+                // Adobe four-component files as stb_image maps them to RGB: transform 0 = CMYK, 2 = YCCK (YCbCr first, then
+                // the inverted result times K), anything else = YCbCr with the fourth component ignored.
+                auto blinn = [](unsigned x, unsigned y) {
+                    unsigned const t = x * y + 128u;
+                    return static_cast<uint8_t>((t + (t >> 8)) >> 8);
+                };
+                auto f2f = [](double x) { return static_cast<int>(static_cast<unsigned>(static_cast<int>(x * 4096.0 + 0.5)) << 8); };
+                int const crR = f2f(1.40200), crG = -f2f(0.71414), cbG = -f2f(0.34414), cbB = f2f(1.77200);
+                for (int i = 0; i < width_; i++)
+                {
+                    unsigned const k = rows[3][i];
+                    if (adobeTransform_ == 0)
+                    {
+                        out[i * 4] = blinn(rows[0][i], k);
+                        out[i * 4 + 1] = blinn(rows[1][i], k);
+                        out[i * 4 + 2] = blinn(rows[2][i], k);
+                        continue;
+                    }
+                    int const yFixed = (rows[0][i] << 20) + (1 << 19);
+                    int const cb = rows[1][i] - 128, cr = rows[2][i] - 128;
+                    int const r = (yFixed + cr * crR) >> 20;
+                    int const g = (yFixed + cr * crG + static_cast<int>(static_cast<unsigned>(cb * cbG) & 0xffff0000u)) >> 20;
+                    int const b = (yFixed + cb * cbB) >> 20;
+                    if (adobeTransform_ == 2)
+                    {
+                        out[i * 4] = blinn(255u - clamp(r), k);
+                        out[i * 4 + 1] = blinn(255u - clamp(g), k);
+                        out[i * 4 + 2] = blinn(255u - clamp(b), k);
+                    }
+                    else
+                    {
+                        out[i * 4] = clamp(r);
+                        out[i * 4 + 1] = clamp(g);
+                        out[i * 4 + 2] = clamp(b);
+                    }
                 }
             }
             else if (isRgb)

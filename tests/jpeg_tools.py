@@ -138,7 +138,11 @@ def encode(image, sampling=((2, 2), (1, 1), (1, 1)), quality=85, restart=0, inte
     default scan script) or a scan script (default_progressive_script)."""
     img = np.asarray(image)
     h, w = img.shape[:2]
-    if img.ndim == 2:
+    if img.ndim == 3 and img.shape[2] == 4:
+        # four components stored as they are (Adobe CMYK / YCCK files); give adobe_transform 0 or 2
+        planes = [img[..., k].astype(np.float64) for k in range(4)]
+        sampling = list(sampling) if len(sampling) == 4 else [(1, 1)] * 4
+    elif img.ndim == 2:
         planes, sampling = [img.astype(np.float64)], [(1, 1)] if sampling is None or len(sampling) != 1 else list(sampling)
     elif rgb_ids or adobe_transform == 0:
         planes = [img[..., k].astype(np.float64) for k in range(3)]
@@ -745,6 +749,30 @@ def decode(data):
                     l1 += 1
         full.append(np.stack(rows))
     out = np.full((h, w, 4), 255, np.uint8)
+
+    def ycc_to_rgb(y, cb, cr):
+        f = lambda x: int(np.float32(x) * np.float32(4096.0) + np.float32(0.5)) << 8  # noqa: E731
+        cb, cr = cb - 128, cr - 128
+        yf = (y << 20) + (1 << 19)
+        masked = ((cb * -f(0.34414)) & 0xFFFFFFFF) & 0xFFFF0000
+        masked = np.where(masked >= (1 << 31), masked - (1 << 32), masked)
+        return [np.clip(v >> 20, 0, 255) for v in (yf + cr * f(1.40200), yf + cr * -f(0.71414) + masked, yf + cb * f(1.77200))]
+
+    def blinn(x, k):
+        t = x * k + 128
+        return (t + (t >> 8)) >> 8
+
+    if n == 4:
+        k4 = full[3]
+        if adobe == 0:
+            rgb = [blinn(full[c], k4) for c in range(3)]
+        else:
+            rgb = ycc_to_rgb(full[0], full[1], full[2])
+            if adobe == 2:
+                rgb = [blinn(255 - v, k4) for v in rgb]
+        for c in range(3):
+            out[..., c] = rgb[c]
+        return out
     if n == 1:
         out[..., 0] = out[..., 1] = out[..., 2] = full[0]
     elif [c["id"] for c in comps] == [ord(x) for x in "RGB"] or (adobe == 0 and not jfif):

@@ -210,6 +210,22 @@ def test_jpeg_colour_spaces_and_table_precisions():
     assert np.abs(g[..., 0].astype(int) - grey.astype(int)).mean() < 2.0
 
 
+@pytest.mark.parametrize("transform", [0, 2, 1])
+def test_jpeg_four_component_adobe_files(transform):
+    """CMYK (transform 0), YCCK (2) and 'YCbCr + ignored fourth component' (anything else) as stb_image maps them to RGB."""
+    y, x = np.mgrid[0:21, 0:33]
+    img = np.stack([(x * 7) % 256, (y * 11) % 256, ((x + y) * 5) % 256, (x * y) % 256], -1).astype(np.uint8)
+    for kw in (dict(), dict(progressive=True), dict(sampling=[(2, 2), (1, 1), (1, 1), (2, 2)], restart=2)):
+        data = jt.encode(img, adobe_transform=transform, quality=92, **kw)
+        got = assets.decode_image_rgba(data)
+        assert (got == jt.decode(data)).all() and (got[..., 3] == 255).all()
+    if transform == 0:
+        # CMYK is stored inverted by Adobe: channel * K / 255 (rounded the way stb_image rounds it), within JPEG's own error
+        flat = np.full((16, 16, 4), (200, 100, 50, 128), np.uint8)
+        got = assets.decode_image_rgba(jt.encode(flat, adobe_transform=0, quality=100, sampling=[(1, 1)] * 4))
+        assert np.abs(got[8, 8, :3].astype(int) - np.array([200 * 128 // 255, 100 * 128 // 255, 50 * 128 // 255])).max() <= 2
+
+
 def test_jpeg_what_is_refused_and_what_is_tolerated():
     img = _picture(33, 17, 2)
     data = jt.encode(img, restart=2)

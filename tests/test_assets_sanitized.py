@@ -39,8 +39,9 @@ def test_asset_loaders_survive_corrupted_input_under_sanitizers(tmp_path):
     seed("a444.jpg.png", jt.encode(picture, sampling=((1, 1),) * 3, interleaved=False, q16=True))
     seed("mixed.jpg.png", jt.encode(picture, sampling=((2, 2), (2, 1), (1, 2)), quality=30))
     seed("progressive.jpg.png", jt.encode(picture, progressive=True, restart=3))
+    seed("cmyk.jpg.png", jt.encode(rng.integers(0, 256, (13, 18, 4), dtype=np.uint8), adobe_transform=2))
     out = subprocess.run([os.path.join(HERE, "cpp", "fuzz_assets"), "4000"] + seeds, capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:allocator_may_return_null=1:max_allocation_size_mb=2048"))
     assert out.returncode == 0, out.stderr[-4000:]
     inputs, loaded = (int(x) for x in out.stdout.split()[::2][:2])
-    assert inputs == 9 * 4001 and 9 <= loaded < inputs
+    assert inputs == 10 * 4001 and 10 <= loaded < inputs
