@@ -895,8 +895,11 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     float const L2 = sampleDistance * sampleDistance + m.two_r_mu * sampleDistance + m.r2;
     float const tStar = -m.r_mu;
     float const rmin2 = (tStar > 0.0f && tStar < sampleDistance) ? m.r2 * (1.0f - mu * mu) : fminf(m.r2, L2);
+    // ... and the two cosines are cosines: a sun (or view) vector of length 0 or inf makes mu_sun (mu) infinite or NaN, and
+    // the one-correction division returns NaN for an infinite numerator where the quotient is inf.
     bool const lean = a.lean && rmin2 >= a.leanFloor2 && inRange(radius, 0x1p-30f, 0x1p30f) && inRange(sampleDistance, 0.0f, 0x1p30f) &&
-                      m.sin_sunRadius >= 0x1p-30f;
+                      m.sin_sunRadius >= 0x1p-30f && leanLength2(sun2) && leanLength2(direction2) && fabsf(mu) <= 2.0f &&
+                      fabsf(mu_sun) <= 2.0f;
     m.extLean = waveAll(a.extModerate && rmin2 >= a.extFloor2 && fmaxf(m.r2, L2) <= a.extCeil2);
     // wave-uniform choice: one lane outside the domain sends its whole wave down the generic path
     if (waveAll(lean))

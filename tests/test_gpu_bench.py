@@ -67,7 +67,7 @@ def test_example_render_gltf_runs(tmp_path):
                                              ("random_sweep_shadow.py", 0, 80), ("random_sweep_raster.py", 21590, 21620),
                                              ("random_sweep_frames.py", 230, 250), ("random_sweep_params_fuzz.py", 1000, 1060),
                                              ("random_sweep_params_fuzz.py", 1500, 1530), ("random_sweep_params_fuzz.py", 26695, 26710), ("random_sweep_params_fuzz.py", 77025, 77032),
-                                             ("random_sweep_params_fuzz.py", 87730, 87736),
+                                             ("random_sweep_params_fuzz.py", 87730, 87736), ("random_sweep_params_fuzz.py", 116586, 116593),
                                              ("random_sweep_raster_fuzz.py", 100, 130),
                                              ("random_sweep_raster_fuzz.py", 1375, 1390), ("random_sweep_raster_fuzz.py", 2920, 2935)])
 def test_random_sweep_tools_find_nothing(tool, first, last, extra=()):
