@@ -30,7 +30,8 @@
  * An image that is not decoded fails like any undecodable image does in the reference (warning, default map kept).
  * The reference holds no usable asset for this path (assets/sphere.glb is a 132-byte LFS pointer): parity unpinned;
  * tests write glTF/GLB/PNG/JPEG files with independent Python encoders and compare array by array (JPEG: against a
- * numpy restatement of the same published arithmetic).
+ * numpy restatement of the same published arithmetic), and decode files written by Pillow (libjpeg-turbo, libpng): PNG
+ * identical to Pillow's own decode, JPEG within 3 LSB of it (tests/golden/images).
  *
  * Where the reference would read out of bounds or trips an assert (accessor past its buffer, attribute longer than
  * POSITION, wrong accessor type) this loader skips the item with a warning instead; every such case is listed in

@@ -226,6 +226,29 @@ def test_jpeg_four_component_adobe_files(transform):
         assert np.abs(got[8, 8, :3].astype(int) - np.array([200 * 128 // 255, 100 * 128 // 255, 50 * 128 // 255])).max() <= 2
 
 
+def test_images_written_and_decoded_by_pillow():
+    """Files from independent encoders (Pillow = libjpeg-turbo / libpng, tests/golden/make_image_fixtures.py) with Pillow's own
+    decode of each: PNG must match exactly; JPEG within 3 LSB (libjpeg-turbo's IDCT and colour conversion round differently
+    from stb_image's) — except the second-to-last column of a 4:2:2 file, where stb_image's horizontal upsampler weights the
+    neighbour with 3/4 (`input[w-2]*3 + input[w-1]`), faithfully restated here, and libjpeg the sample itself."""
+    folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "images")
+    expected = np.load(os.path.join(folder, "expected_rgba.npz"))
+    assert len(expected.files) == 17
+    for name in expected.files:
+        got = assets.decode_image_rgba(open(os.path.join(folder, name), "rb").read())
+        want = expected[name]
+        assert got.shape == want.shape, name
+        diff = np.abs(got.astype(int) - want.astype(int))
+        if name.endswith(".png"):
+            assert diff.max() == 0, name
+            continue
+        if name == "baseline_422.jpg":
+            assert diff[:, -2].max() > 4  # the documented stb_image edge rule
+            diff[:, -2] = 0
+        assert diff.max() <= 3 and diff.mean() < 0.2, (name, diff.max(), diff.mean())
+        assert (got == jt.decode(open(os.path.join(folder, name), "rb").read())).all(), name  # and the numpy restatement agrees bit for bit
+
+
 def test_jpeg_what_is_refused_and_what_is_tolerated():
     img = _picture(33, 17, 2)
     data = jt.encode(img, restart=2)
