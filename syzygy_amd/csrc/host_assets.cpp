@@ -511,6 +511,34 @@ class Inflater
 
     bool zlib(Bytes& out, size_t limit)
     {
+        out.resize(limit); // written through data_ / size_ (no per-byte push_back); trimmed to what was produced at the end
+        data_ = out.data();
+        size_ = 0;
+        bool const ok = stream(limit);
+        out.resize(size_);
+        return ok;
+    }
+
+  private:
+    static constexpr int FAST_BITS = 10;
+    struct Huffman
+    {
+        uint16_t fast[1 << FAST_BITS]; // (length << 9) | symbol, 0 = not a short code
+        uint16_t count[16];
+        uint16_t symbol[288];
+    };
+
+    const uint8_t* p_;
+    const uint8_t* end_;
+    uint8_t* data_ = nullptr; // output buffer of `limit` bytes and the number of bytes produced so far
+    size_t size_ = 0;
+    uint64_t hold_ = 0;
+    int held_ = 0;    // bits in hold_, including ...
+    int phantom_ = 0; // ... zero bits appended past the end of the input (look-ahead of decode())
+    Huffman lit_{}, dist_{};
+
+    bool stream(size_t limit)
+    {
         if (end_ - p_ < 2)
         {
             return false;
@@ -528,16 +556,16 @@ class Inflater
             bool ok;
             if (type == 0)
             {
-                ok = stored(out, limit);
+                ok = stored(limit);
             }
             else if (type == 1)
             {
                 fixedTables();
-                ok = block(out, limit);
+                ok = block(limit);
             }
             else if (type == 2)
             {
-                ok = dynamicTables() && block(out, limit);
+                ok = dynamicTables() && block(limit);
             }
             else
             {
@@ -553,22 +581,6 @@ class Inflater
             }
         }
     }
-
-  private:
-    static constexpr int FAST_BITS = 10;
-    struct Huffman
-    {
-        uint16_t fast[1 << FAST_BITS]; // (length << 9) | symbol, 0 = not a short code
-        uint16_t count[16];
-        uint16_t symbol[288];
-    };
-
-    const uint8_t* p_;
-    const uint8_t* end_;
-    uint64_t hold_ = 0;
-    int held_ = 0;    // bits in hold_, including ...
-    int phantom_ = 0; // ... zero bits appended past the end of the input (look-ahead of decode())
-    Huffman lit_{}, dist_{};
 
     // true once bits that are not in the input have been consumed
     bool overrun() const { return held_ < phantom_; }
@@ -689,13 +701,13 @@ class Inflater
         }
         return -1;
     }
-    bool stored(Bytes& out, size_t limit)
+    bool stored(size_t limit)
     {
         hold_ >>= (held_ & 7);
         held_ -= (held_ & 7);
         unsigned const len = bits(16);
         unsigned const nlen = bits(16);
-        if (overrun() || (len ^ 0xFFFFu) != nlen)
+        if (overrun() || (len ^ 0xFFFFu) != nlen || size_ + len > limit)
         {
             return false;
         }
@@ -703,16 +715,17 @@ class Inflater
         unsigned remaining = len;
         while (remaining > 0 && held_ >= 8)
         {
-            out.push_back(static_cast<uint8_t>(hold_ & 0xFFu));
+            data_[size_++] = static_cast<uint8_t>(hold_ & 0xFFu);
             hold_ >>= 8;
             held_ -= 8;
             remaining--;
         }
-        if (static_cast<size_t>(end_ - p_) < remaining || out.size() + remaining > limit)
+        if (static_cast<size_t>(end_ - p_) < remaining)
         {
             return false;
         }
-        out.insert(out.end(), p_, p_ + remaining);
+        std::memcpy(data_ + size_, p_, remaining);
+        size_ += remaining;
         p_ += remaining;
         return true;
     }
@@ -799,7 +812,7 @@ class Inflater
         }
         return build(lit_, lengths, nlen) && build(dist_, lengths + nlen, ndist);
     }
-    bool block(Bytes& out, size_t limit)
+    bool block(size_t limit)
     {
         static const uint16_t lengthBase[29] = {3,  4,  5,  6,  7,  8,  9,  10, 11,  13,  15,  17,  19,  23, 27,
                                                 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
@@ -816,11 +829,11 @@ class Inflater
             }
             if (sym < 256)
             {
-                if (out.size() >= limit)
+                if (size_ >= limit)
                 {
                     return false;
                 }
-                out.push_back(static_cast<uint8_t>(sym));
+                data_[size_++] = static_cast<uint8_t>(sym);
                 continue;
             }
             if (sym == 256)
@@ -839,15 +852,17 @@ class Inflater
                 return false;
             }
             size_t const distance = distBase[di] + bits(distExtra[di]);
-            if (distance > out.size() || out.size() + length > limit)
+            if (distance > size_ || size_ + length > limit)
             {
                 return false;
             }
-            size_t const from = out.size() - distance;
-            for (size_t k = 0; k < length; k++)
+            const uint8_t* from = data_ + (size_ - distance);
+            uint8_t* to = data_ + size_;
+            for (size_t k = 0; k < length; k++) // forward byte copy: source and destination may overlap (run-length matches)
             {
-                out.push_back(out[from + k]);
+                to[k] = from[k];
             }
+            size_ += length;
         }
     }
 };
@@ -1043,8 +1058,12 @@ bool decodePng(const uint8_t* data, size_t size, uint32_t& width, uint32_t& heig
             expected += (static_cast<size_t>((static_cast<uint64_t>(pw) * bitsPerPixel + 7) / 8) + 1) * ph;
         }
     }
+    if (expected / 1032u > compressed.size() + 1u)
+    {
+        why = "corrupt PNG image data"; // deflate cannot expand by more than 1032 : 1: the header promises more than the data holds
+        return false;
+    }
     Bytes raw;
-    raw.reserve(expected);
     Inflater inflater(compressed.data(), compressed.size());
     if (!inflater.zlib(raw, expected) || raw.size() < expected)
     {
@@ -1077,30 +1096,72 @@ bool decodePng(const uint8_t* data, size_t size, uint32_t& width, uint32_t& heig
                 why = "bad PNG filter";
                 return false;
             }
-            for (size_t i = 0; i < rowBytes; i++)
+            uint8_t* const cur = current.data();
+            const uint8_t* const up = previous.data();
+            size_t const head = std::min(filterStride, rowBytes); // bytes without a left neighbour
+            switch (filter)
             {
-                int const a = i >= filterStride ? current[i - filterStride] : 0;
-                int const b = previous[i];
-                int const c = i >= filterStride ? previous[i - filterStride] : 0;
-                int predictor = 0;
-                switch (filter)
+            case 0: std::memcpy(cur, in, rowBytes); break;
+            case 1:
+                std::memcpy(cur, in, head);
+                for (size_t i = head; i < rowBytes; i++)
                 {
-                case 1: predictor = a; break;
-                case 2: predictor = b; break;
-                case 3: predictor = (a + b) >> 1; break;
-                case 4:
+                    cur[i] = static_cast<uint8_t>(in[i] + cur[i - filterStride]);
+                }
+                break;
+            case 2:
+                for (size_t i = 0; i < rowBytes; i++)
                 {
-                    int const p = a + b - c;
-                    int const pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                    predictor = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    break;
+                    cur[i] = static_cast<uint8_t>(in[i] + up[i]);
                 }
-                default: break;
+                break;
+            case 3:
+                for (size_t i = 0; i < head; i++)
+                {
+                    cur[i] = static_cast<uint8_t>(in[i] + (up[i] >> 1));
                 }
-                current[i] = static_cast<uint8_t>(in[i] + predictor);
+                for (size_t i = head; i < rowBytes; i++)
+                {
+                    cur[i] = static_cast<uint8_t>(in[i] + ((cur[i - filterStride] + up[i]) >> 1));
+                }
+                break;
+            default: // Paeth
+                for (size_t i = 0; i < head; i++)
+                {
+                    cur[i] = static_cast<uint8_t>(in[i] + up[i]); // a = c = 0: the predictor is b
+                }
+                for (size_t i = head; i < rowBytes; i++)
+                {
+                    int const a = cur[i - filterStride], b = up[i], c = up[i - filterStride];
+                    int const pp = a + b - c;
+                    int const pa = std::abs(pp - a), pb = std::abs(pp - b), pc = std::abs(pp - c);
+                    cur[i] = static_cast<uint8_t>(in[i] + ((pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c)));
+                }
+                break;
             }
             // samples of this row -> RGBA8
             uint8_t* const outRow = rgba.data() + (static_cast<size_t>(ps.y0 + j * ps.dy) * width) * 4;
+            if (depth == 8 && ps.dx == 1 && (colorType == 6 || (colorType == 2 && !hasKey)))
+            {
+                // the common layouts, a row at a time (same values as the general path below)
+                if (colorType == 6)
+                {
+                    std::memcpy(outRow, current.data(), static_cast<size_t>(pw) * 4);
+                }
+                else
+                {
+                    const uint8_t* src = current.data();
+                    for (uint32_t i = 0; i < pw; i++)
+                    {
+                        outRow[i * 4] = src[i * 3];
+                        outRow[i * 4 + 1] = src[i * 3 + 1];
+                        outRow[i * 4 + 2] = src[i * 3 + 2];
+                        outRow[i * 4 + 3] = 255;
+                    }
+                }
+                previous.swap(current);
+                continue;
+            }
             for (uint32_t i = 0; i < pw; i++)
             {
                 uint32_t sample[4] = {0, 0, 0, 0};
