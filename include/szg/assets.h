@@ -127,6 +127,9 @@ int szg_default_mesh(int kind, szg_asset_mesh* out);
 
 /* detail_stbi::loadRGBA (assets.cpp:319-364): PNG or JPEG bytes -> RGBA8. The caller frees *out_rgba with szg_free_rgba. */
 int szg_decode_image_rgba(const void* bytes, size_t size, uint32_t* out_width, uint32_t* out_height, uint8_t** out_rgba);
+/* The file part of AssetLibrary::loadTextureFromPath (assets.cpp:1131-1168): read the file, decode it as above.
+ * SZG_ERR_IO if it cannot be read ("Failed to open file for texture."), SZG_ERR_PARSE if it cannot be decoded. */
+int szg_load_image_file_rgba(const char* path, uint32_t* out_width, uint32_t* out_height, uint8_t** out_rgba);
 void szg_free_rgba(uint8_t* rgba);
 
 #ifdef __cplusplus

@@ -224,24 +224,12 @@ class AssetLibrary
     // assets.cpp:1131-1168 (fileFormat: sRGB or UNORM interpretation of the 8-bit texels)
     auto loadTextureFromPath(bool srgb, std::filesystem::path const& filePath) -> std::shared_ptr<ImageView const>
     {
-        std::FILE* file = std::fopen(filePath.string().c_str(), "rb");
-        if (file == nullptr)
-        {
-            std::fprintf(stderr, "[szg] Failed to open file for texture.\n");
-            return nullptr;
-        }
-        std::vector<uint8_t> bytes;
-        uint8_t chunk[65536];
-        for (size_t n; (n = std::fread(chunk, 1, sizeof chunk, file)) > 0;)
-        {
-            bytes.insert(bytes.end(), chunk, chunk + n);
-        }
-        std::fclose(file);
         uint32_t width = 0, height = 0;
         uint8_t* rgba = nullptr;
-        if (szg_decode_image_rgba(bytes.data(), bytes.size(), &width, &height, &rgba) != SZG_OK)
+        if (int const status = szg_load_image_file_rgba(filePath.string().c_str(), &width, &height, &rgba); status != SZG_OK)
         {
-            std::fprintf(stderr, "[szg] Failed to convert file to 32 bit RGBA image.\n");
+            std::fprintf(stderr, status == SZG_ERR_IO ? "[szg] Failed to open file for texture.\n"
+                                                     : "[szg] Failed to convert file to 32 bit RGBA image.\n");
             return nullptr;
         }
         auto view = ImageView::upload(rgba, width, height, srgb, deduplicateAssetName("texture_" + filePath.stem().string()));

@@ -450,6 +450,7 @@ ASSET_FUNCTIONS = {
     "szg_default_material_map": (C.c_int, [C.c_int, P(C.c_uint8)]),
     "szg_default_mesh": (C.c_int, [C.c_int, P(AssetMesh)]),
     "szg_decode_image_rgba": (C.c_int, [VP, C.c_size_t, P(U32), P(U32), P(P(C.c_uint8))]),
+    "szg_load_image_file_rgba": (C.c_int, [C.c_char_p, P(U32), P(U32), P(P(C.c_uint8))]),
     "szg_free_rgba": (None, [P(C.c_uint8)]),
 }
 

@@ -43,6 +43,18 @@ def decode_image_rgba(data):
         lib().szg_free_rgba(ptr)
 
 
+def load_image_rgba(path):
+    """The file part of AssetLibrary::loadTextureFromPath (assets.cpp:1131-1168): an image file -> uint8 [h, w, 4]."""
+    w, h, ptr = abi.U32(), abi.U32(), C.POINTER(C.c_uint8)()
+    status = lib().szg_load_image_file_rgba(os.fsencode(path), C.byref(w), C.byref(h), C.byref(ptr))
+    if status != abi.SZG_OK:
+        raise AssetError(f"{_last_error()} (status {status})")
+    try:
+        return np.frombuffer(C.string_at(ptr, h.value * w.value * 4), np.uint8).reshape(h.value, w.value, 4).copy()
+    finally:
+        lib().szg_free_rgba(ptr)
+
+
 class GltfMesh:
     """One loaded Mesh (assets.hpp:30-44): packed vertices, rebased indices, surfaces, bounds."""
 

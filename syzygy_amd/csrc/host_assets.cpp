@@ -2302,6 +2302,23 @@ int szg_decode_image_rgba(const void* bytes, size_t size, uint32_t* out_width, u
     }
 }
 
+int szg_load_image_file_rgba(const char* path, uint32_t* out_width, uint32_t* out_height, uint8_t** out_rgba)
+{
+    if (path == nullptr || out_width == nullptr || out_height == nullptr || out_rgba == nullptr)
+    {
+        szg::set_last_error("szg_load_image_file_rgba: NULL argument");
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    *out_rgba = nullptr;
+    Bytes bytes;
+    if (!readFile(path, bytes) || bytes.empty())
+    {
+        szg::set_last_error("Failed to open file for texture."); // assets.cpp:1143-1147
+        return SZG_ERR_IO;
+    }
+    return szg_decode_image_rgba(bytes.data(), bytes.size(), out_width, out_height, out_rgba);
+}
+
 void szg_free_rgba(uint8_t* rgba) { std::free(rgba); }
 
 } // extern "C"

@@ -249,6 +249,18 @@ def test_images_written_and_decoded_by_pillow():
         assert (got == jt.decode(open(os.path.join(folder, name), "rb").read())).all(), name  # and the numpy restatement agrees bit for bit
 
 
+def test_image_files_load_by_path(tmp_path):
+    folder = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "images")
+    expected = np.load(os.path.join(folder, "expected_rgba.npz"))
+    assert (assets.load_image_rgba(os.path.join(folder, "rgba.png")) == expected["rgba.png"]).all()
+    assert assets.load_image_rgba(os.path.join(folder, "progressive_420.jpg")).shape == expected["progressive_420.jpg"].shape
+    with pytest.raises(assets.AssetError, match="Failed to open file for texture"):
+        assets.load_image_rgba(str(tmp_path / "missing.png"))
+    (tmp_path / "text.png").write_bytes(b"not an image")
+    with pytest.raises(assets.AssetError, match="status -7"):
+        assets.load_image_rgba(str(tmp_path / "text.png"))
+
+
 def test_jpeg_what_is_refused_and_what_is_tolerated():
     img = _picture(33, 17, 2)
     data = jt.encode(img, restart=2)
