@@ -17,21 +17,18 @@
  *                                                 bounds = AABB::create(min, max) of the positions
  *   default maps             assets.cpp:1294-1398 64x64 checkerboard colour, flat normal, (255, 60, 0) ORM
  *
- * The parsing itself is third-party code in the reference and NOT under /root/reference: fastgltf (glTF, base64, accessor
- * tools; cmake/dependencies.cmake) and stb_image (image decoding, thirdparty include). Their published behaviour is
- * restated: glTF 2.0 accessors (all component types, `normalized`, byteStride, sparse), GLB containers, data: URIs;
- * the two image encodings glTF 2.0 allows, decoded as stb_image does for a 4-channel request:
- *   PNG   bit depths 1-16, all colour types, tRNS, Adam7; 16-bit samples keep their high byte; gamma chunks ignored;
- *         checksums not verified
- *   JPEG  baseline / extended-sequential / progressive Huffman, 8 bit, grey, three components or four (Adobe CMYK /
- *         YCCK) with any sampling factors, restart intervals, interleaved or per-component scans; stb_image's integer inverse DCT,
- *         triangle-filter chroma upsampling and fixed-point YCbCr conversion (syzygy_amd/csrc/host_jpeg.cpp).
- *         Arithmetic-coded, lossless and 12-bit files are NOT decoded.
+ * Asset IO is OUT OF SCOPE of the hot path; this loader exists only so that the rasteriser's
+ * tests can be fed meshes and maps from files, and it is frozen. The glTF parsing is third-party code in the reference
+ * (fastgltf, a FetchContent download that is not in the checkout); image decoding is stb_image, vendored under
+ * thirdparty/stb. glTF 2.0 accessors (all component types, `normalized`, byteStride, sparse), GLB containers and data:
+ * URIs are read from the glTF 2.0 specification. Of the two image encodings glTF 2.0 allows only PNG is decoded
+ * (RFC 1951 / the PNG specification: bit depths 1-16, all colour types, tRNS, Adam7; 16-bit samples keep their high
+ * byte and gamma chunks are ignored, as a 4-channel 8-bit request to the reference's decoder answers; checksums not
+ * verified). JPEG is NOT decoded.
  * An image that is not decoded fails like any undecodable image does in the reference (warning, default map kept).
  * The reference holds no usable asset for this path (assets/sphere.glb is a 132-byte LFS pointer): parity unpinned;
- * tests write glTF/GLB/PNG/JPEG files with independent Python encoders and compare array by array (JPEG: against a
- * numpy restatement of the same published arithmetic), and decode files written by Pillow (libjpeg-turbo, libpng): PNG
- * identical to Pillow's own decode, JPEG within 3 LSB of it (tests/golden/images).
+ * tests write glTF/GLB/PNG files with an independent Python encoder and compare array by array, and decode PNG files
+ * written by Pillow (libpng): identical to Pillow's own decode (tests/golden/images).
  *
  * Where the reference would read out of bounds or trips an assert (accessor past its buffer, attribute longer than
  * POSITION, wrong accessor type) this loader skips the item with a warning instead; every such case is listed in
@@ -125,7 +122,7 @@ int szg_default_material_map(int kind, uint8_t* rgba);
 #define SZG_DEFAULT_MESH_PLANE 1
 int szg_default_mesh(int kind, szg_asset_mesh* out);
 
-/* detail_stbi::loadRGBA (assets.cpp:319-364): PNG or JPEG bytes -> RGBA8. The caller frees *out_rgba with szg_free_rgba. */
+/* detail_stbi::loadRGBA (assets.cpp:319-364): PNG bytes -> RGBA8 (a JPEG stream is SZG_ERR_PARSE). The caller frees *out_rgba with szg_free_rgba. */
 int szg_decode_image_rgba(const void* bytes, size_t size, uint32_t* out_width, uint32_t* out_height, uint8_t** out_rgba);
 /* The file part of AssetLibrary::loadTextureFromPath (assets.cpp:1131-1168): read the file, decode it as above.
  * SZG_ERR_IO if it cannot be read ("Failed to open file for texture."), SZG_ERR_PARSE if it cannot be decoded. */

@@ -30,7 +30,7 @@ def default_material_map(kind):
 
 
 def decode_image_rgba(data):
-    """detail_stbi::loadRGBA (assets.cpp:319-364): encoded image bytes -> uint8 [h, w, 4]. PNG or JPEG."""
+    """detail_stbi::loadRGBA (assets.cpp:319-364): PNG bytes -> uint8 [h, w, 4] (JPEG is refused)."""
     data = bytes(data)
     w, h, ptr = abi.U32(), abi.U32(), C.POINTER(C.c_uint8)()
     buf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")

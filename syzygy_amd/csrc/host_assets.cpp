@@ -1,6 +1,8 @@
 // host_assets.cpp — szg/assets.h: glTF 2.0 / GLB -> meshes, surfaces and material maps for the raster passes
 // (assets/assets.cpp:406-1092, :1192-1266). CPU only, no third-party code: a small JSON reader, base64, inflate and a
-// PNG decoder stand where the reference calls fastgltf and stb_image (neither is under /root/reference).
+// PNG decoder stand where the reference calls fastgltf (a FetchContent download, not in the checkout) and stb_image
+// (vendored under thirdparty/stb; not used or restated here — PNG is decoded from its specification, JPEG is refused).
+// Out of the hot path's scope and frozen: it only feeds the rasteriser's tests.
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
@@ -880,7 +882,10 @@ bool decodeImageBytes(const uint8_t* data, size_t size, uint32_t& width, uint32_
 {
     if (size >= 2 && data[0] == 0xFF && data[1] == 0xD8)
     {
-        return szg::decode_jpeg(data, size, width, height, rgba, why);
+        // asset IO is outside the hot path: PNG only; a JPEG fails like any undecodable image
+        // does in the reference (assets.cpp:336-343: "stbi: Failed to convert image." and the default map)
+        why = "JPEG streams are not decoded by this build (PNG only)";
+        return false;
     }
     return decodePng(data, size, width, height, rgba, why);
 }
@@ -890,7 +895,7 @@ bool decodePng(const uint8_t* data, size_t size, uint32_t& width, uint32_t& heig
     static const uint8_t signature[8] = {137, 80, 78, 71, 13, 10, 26, 10};
     if (size < 8 || std::memcmp(data, signature, 8) != 0)
     {
-        why = "neither a PNG nor a JPEG (the image encodings this build decodes)";
+        why = "not a PNG (the image encoding this build decodes)";
         return false;
     }
     size_t at = 8;

@@ -1,7 +1,7 @@
-"""Image fixtures written by INDEPENDENT encoders (Pillow 12 = libjpeg-turbo + libpng/zlib) together with Pillow's own decode of each,
+"""PNG fixtures written by an INDEPENDENT encoder (Pillow 12 = libpng/zlib) together with Pillow's own decode of each,
 for tests/test_assets.py::test_images_written_and_decoded_by_pillow. Run with an interpreter that has Pillow (in the build
 container: /opt/conda/bin/python tests/golden/make_image_fixtures.py); the product and the test suite never import Pillow.
-PNG decodes must be identical; JPEG decodes agree to a few LSB (libjpeg-turbo and stb_image use different integer IDCTs)."""
+PNG decodes must be identical. (JPEG is not decoded by this build: asset IO is out of the hot path's scope)"""
 import io
 import os
 
@@ -25,27 +25,12 @@ def keep(name, data):
     expected[name] = np.array(Image.open(io.BytesIO(data)).convert("RGBA"))
 
 
-def jpeg(name, image, **kw):
-    b = io.BytesIO()
-    image.save(b, "JPEG", **kw)
-    keep(name, b.getvalue())
-
-
 def png(name, image, **kw):
     b = io.BytesIO()
     image.save(b, "PNG", **kw)
     keep(name, b.getvalue())
 
 
-jpeg("baseline_420.jpg", img, quality=88)
-jpeg("baseline_444_optimized.jpg", img, quality=92, subsampling=0, optimize=True)
-jpeg("baseline_422.jpg", img, quality=80, subsampling=1)
-jpeg("progressive_420.jpg", img, quality=85, progressive=True)
-jpeg("progressive_444.jpg", img, quality=95, subsampling=0, progressive=True, optimize=True)
-jpeg("grey.jpg", img.convert("L"), quality=90)
-jpeg("grey_progressive.jpg", img.convert("L"), quality=75, progressive=True)
-jpeg("restart.jpg", img, quality=85, restart_marker_blocks=2)
-jpeg("cmyk.jpg", img.convert("CMYK"), quality=90)
 png("rgb.png", img)
 png("rgba.png", Image.fromarray(np.dstack([rgb, ((x * 5 + y * 3) % 256).astype(np.uint8)]), "RGBA"), compress_level=9)
 png("grey.png", img.convert("L"))

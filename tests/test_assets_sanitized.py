@@ -7,7 +7,6 @@ import subprocess
 import numpy as np
 
 from tests import gltf_writer as gw
-from tests import jpeg_tools as jt
 from tests.test_assets import _two_primitive_asset
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -33,15 +32,8 @@ def test_asset_loaders_survive_corrupted_input_under_sanitizers(tmp_path):
     seed("rgba.png", gw.png_rgba8(rng.integers(0, 256, (23, 31, 4), dtype=np.uint8), idat_split=100))
     seed("pal.png", gw.png_encode(rng.integers(0, 4, (17, 9, 1)), 3, 2, palette=rng.integers(0, 256, (4, 3)), trns=bytes([1, 2]), interlace=True))
     seed("g16.png", gw.png_encode(rng.integers(0, 65536, (8, 8, 2)), 4, 16, interlace=True, level=0))
-    # JPEG seeds carry a ".png" suffix: the harness routes that suffix to szg_decode_image_rgba, which sniffs the encoding
-    picture = rng.integers(0, 256, (19, 27, 3), dtype=np.uint8)
-    seed("a420.jpg.png", jt.encode(picture, restart=2))
-    seed("a444.jpg.png", jt.encode(picture, sampling=((1, 1),) * 3, interleaved=False, q16=True))
-    seed("mixed.jpg.png", jt.encode(picture, sampling=((2, 2), (2, 1), (1, 2)), quality=30))
-    seed("progressive.jpg.png", jt.encode(picture, progressive=True, restart=3))
-    seed("cmyk.jpg.png", jt.encode(rng.integers(0, 256, (13, 18, 4), dtype=np.uint8), adobe_transform=2))
     out = subprocess.run([os.path.join(HERE, "cpp", "fuzz_assets"), "4000"] + seeds, capture_output=True, text=True, timeout=900,
                          env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:allocator_may_return_null=1:max_allocation_size_mb=2048"))
     assert out.returncode == 0, out.stderr[-4000:]
     inputs, loaded = (int(x) for x in out.stdout.split()[::2][:2])
-    assert inputs == 10 * 4001 and 10 <= loaded < inputs
+    assert inputs == 5 * 4001 and 5 <= loaded < inputs
