@@ -79,8 +79,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE {world} != --gpus {args.gpus}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU yet (importing torch does
+        # not), so it may start the N ranks itself - as CHILD processes, never by exec - relay rank 0's JSON line and
+        # leave with their status.
+        sys.exit(self_launch(args.gpus, real_stdout))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.same_device:
@@ -447,6 +450,35 @@ def main():
         dist.destroy_process_group()
     deferred.cleanup()
     sky.destroy()
+
+
+def self_launch(nproc, real_stdout):
+    """Start `nproc` ranks of this script under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1 at a
+    free port), pass the one JSON line of rank 0 through to the saved stdout descriptor and return the launcher's status."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("self-launch:", " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    child = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env)
+    lines = 0
+    for raw in child.stdout:
+        text = raw.decode("utf-8", "replace")
+        if text.lstrip().startswith('{"metric"'):
+            os.write(real_stdout, raw)
+            lines += 1
+        else:
+            sys.stderr.write(text)
+    status = child.wait()
+    if status == 0 and lines != 1:
+        log(f"self-launch: expected one JSON line from rank 0, saw {lines}")
+        return 1
+    return status
 
 
 def cpu_baseline(args, wl, atm, cam, sun, moon, spots, syn):

@@ -30,12 +30,25 @@ def test_bench_contract_and_two_rank_rehearsal():
         assert key in one, key
     assert one["n_gpus"] == 1 and one["unit"] == "Mpixels/s" and one["dtype"] == "f32" and one["vs_baseline"] is None
     assert one["roofline"]["bound"] == "hbm" and 0 < one["roofline"]["frac"] < 1
-    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                "--master-port", "29655", "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "2", "--warmup", "1",
+    # `python bench.py --gpus 2` with no launcher around it: bench.py starts its own ranks (self_launch) and relays the line
+    two = _run([sys.executable, "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "2", "--warmup", "1",
                 "--no-cpu-baseline"])
     assert two["n_gpus"] == 2 and two["scaling"] == "strong" and two["config"]["parallelism"] == "rowtile2+gather"
     assert two["image_checksum"] == one["image_checksum"]
     assert abs(two["config"]["geometry_fraction"] - one["config"]["geometry_fraction"]) < 1e-12
+
+
+def test_bench_under_an_external_launcher_and_forced_tiling_on_rccl():
+    """The driver's N > 1 form (torch.distributed.run around bench.py) with the two-rank rehearsal, and the row-tiled loop
+    with both collectives on RCCL in a world of one."""
+    two = _run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                "--master-port", "29655", "bench.py", "--gpus", "2", "--backend", "gloo", "--same-device", "--steps", "1", "--warmup", "1",
+                "--no-cpu-baseline"])
+    assert two["n_gpus"] == 2 and two["config"]["collectives"] == "gloo"
+    one = _run([sys.executable, "bench.py", "--gpus", "1", "--workload", "c4", "--force-tiled", "--steps", "2", "--warmup", "1",
+                "--no-cpu-baseline"])
+    assert one["config"]["collectives"] == "nccl" and one["config"]["parallelism"] == "rowtile1+gather"
+    assert one["image_checksum"] == two["image_checksum"]
 
 
 def test_example_frame_loop_runs():

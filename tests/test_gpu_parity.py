@@ -956,3 +956,106 @@ def test_4k_frame_properties(gpu):
     rows = util.global_rows(H, band_rows, rank, nranks)
     lsb = np.abs(q1[rows].astype(np.int32) - frame.color.astype(np.int32))
     assert lsb.max() <= 1, lsb.max()
+
+
+def _oracle_band(gpu, inp, band_rows, fraction, host_maps, tlut, slut, threads=16):
+    """The oracle's render of `band_rows` rows of the frame starting at `fraction` of its height (contiguous tiling = one
+    block per rank): fill -> lights -> composite on those rows. Returns (global row indices, HostFrame)."""
+    H = inp.height
+    nranks = H // band_rows
+    rank = int(fraction * nranks)
+    tile = util.rowtile(H, band_rows, rank, nranks)
+    assert tile.local_rows == band_rows
+    frame = gpu.ob.HostFrame(inp.width, band_rows)
+    gpu.ob.gbuffer_fill(frame, inp.rect, tile, inp.cam, inp.synthetic.fill, threads=threads)
+    gpu.ob.lights(frame, inp.rect, tile, host_maps, inp.cam, inp.dirs, 2, 1, inp.spots, inp.spot_count, threads=threads)
+    gpu.ob.composite(frame, inp.rect, tile, host_maps, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=threads)
+    return util.global_rows(H, band_rows, rank, nranks), frame
+
+
+def test_c2_full_size_frame_chain(gpu):
+    """BASELINE config 2 at its own size: 1920x1080, no spot lights, the sun by the composite (skip count 1) through a
+    pipeline-owned 2048^2 sun shadow map generated by recordDrawCommands, the moon by the lights pass, both LUTs at the
+    reference's extents (512x128, 2048x1024). The whole chain runs on the GPU; deterministic, finite, opaque; the sun
+    shadow map and BOTH LUTs are compared with the oracle's in full, and two 24-row bands (one across the horizon, one in
+    the shadowed geometry) with the oracle's chained render of the same rows."""
+    W, H, DIM = 1920, 1080, 2048
+    inp = util.Inputs(W, H, elevation_degrees=35.0, spots=0)
+    cameras, atmospheres, lights = staged(gpu, inp)
+
+    def render():
+        target = gpu.pl.SceneTexture(W, H, debug=True)
+        deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=1, max_shadow_maps=1, shadow_map_dim=DIM)
+        sky = gpu.pl.SkyViewComputePipeline.create()
+        deferred.recordDrawCommands(None, inp.rect, target, 1, lights, None, 0, cameras, inp.synthetic.fill)
+        sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+        torch.cuda.synchronize()
+        from syzygy_amd.pipelines import _memcpy2d_from
+
+        sm = deferred.shadowMaps()
+        assert sm.count == 1 and (sm.maps[0].width, sm.maps[0].height) == (DIM, DIM)
+        shadow = _memcpy2d_from(sm.maps[0], DIM * 4, DIM).cpu().numpy().view(np.float32).reshape(DIM, DIM)
+        out = (target.debug.cpu().numpy(), target.color_numpy(), shadow, sky.download_lut(sky.transmittanceLUT()),
+               sky.download_lut(sky.skyviewLUT()))
+        deferred.cleanup()
+        sky.destroy()
+        return out
+
+    dbg, q, shadow, g_tlut, g_slut = render()
+    dbg2, q2, _, _, _ = render()
+    assert (q == q2).all() and (dbg.view(np.uint32) == dbg2.view(np.uint32)).all(), "non-deterministic output"
+    assert np.isfinite(dbg).all() and (q[..., 3] == 65535).all()
+    assert q[: H // 4, :, 2].mean() > q[: H // 4, :, 0].mean(), "daytime sky should be blue"
+
+    want_shadow = gpu.ob.shadow_map(inp.sun, DIM, inp.synthetic.fill, threads=16)
+    assert (shadow.view(np.uint32) == want_shadow.view(np.uint32)).all(), "2048^2 sun shadow map"
+    assert 0.05 < (want_shadow > 0).mean() < 0.95
+    tlut = gpu.ob.transmittance_lut(inp.atm, 512, 128, threads=16)
+    slut = gpu.ob.skyview_lut(inp.atm, inp.cam, tlut, 2048, 1024, threads=16)
+    assert_close(g_tlut, tlut, atol=1e-12, what="C2 transmittance LUT 512x128")
+    assert_close(g_slut[..., :3], slut[..., :3], atol=1e-9, what="C2 sky-view LUT 2048x1024 (whole)")
+
+    images = (gpu.abi.Image * 1)(gpu.ob.host_image(want_shadow, gpu.abi.SZG_FORMAT_D32_SFLOAT))
+    host_maps = gpu.abi.ShadowMaps(1, 0, C.cast(images, C.POINTER(gpu.abi.Image)))
+    shadowed_px = 0
+    for fraction in (0.42, 0.8):
+        rows, frame = _oracle_band(gpu, inp, 24, fraction, host_maps, tlut, slut)
+        assert_close(dbg[rows], frame.debug, what=f"C2 band at {fraction}")
+        lsb = np.abs(q[rows].astype(np.int32) - frame.color.astype(np.int32))
+        assert lsb.max() <= 1, (fraction, lsb.max())
+        # the sun's shadow map does something on these rows: the same band without it differs
+        _, lit = _oracle_band(gpu, inp, 24, fraction, None, tlut, slut)
+        shadowed_px += int((lit.color != frame.color).any(axis=-1).sum())
+        print(f"C2 band at {fraction}: geometry {float((frame.depth > 0).mean()):.2f}, max UNORM16 diff {lsb.max()} LSB")
+    assert shadowed_px > 1000, shadowed_px
+
+
+def test_c5_full_size_frame_chain(gpu):
+    """BASELINE config 5, one view at its own size: 3840x2160 with 256 spot lights, both LUTs at the reference's extents,
+    whole chain on the GPU; deterministic, finite, opaque; two 24-row bands (across the horizon and deep in the lit
+    geometry) against the oracle's chained render of the same rows. The sky-view LUT is the GPU's on both sides here (the
+    oracle's full-size LUT is compared in the C2 test)."""
+    W, H, SPOTS = 3840, 2160, 256
+    inp = util.Inputs(W, H, elevation_degrees=35.0, spots=SPOTS)
+    assert inp.spot_count == SPOTS
+    dbg, q = render_gpu(gpu, inp, lut=((512, 128), (2048, 1024)))
+    dbg2, q2 = render_gpu(gpu, inp, lut=((512, 128), (2048, 1024)))
+    assert (q == q2).all() and (dbg.view(np.uint32) == dbg2.view(np.uint32)).all(), "non-deterministic output"
+    assert np.isfinite(dbg).all() and (q[..., 3] == 65535).all()
+
+    tlut = gpu.ob.transmittance_lut(inp.atm, 512, 128, threads=16)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    skyp = gpu.pl.SkyViewComputePipeline.create()
+    skyp.upload_lut(skyp.transmittanceLUT(), tlut)
+    skyp.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    torch.cuda.synchronize()
+    slut = skyp.download_lut(skyp.skyviewLUT())
+    skyp.destroy()
+    for fraction in (0.42, 0.7):
+        rows, frame = _oracle_band(gpu, inp, 24, fraction, None, tlut, slut)
+        assert_close(dbg[rows], frame.debug, what=f"C5 band at {fraction}")
+        lsb = np.abs(q[rows].astype(np.int32) - frame.color.astype(np.int32))
+        assert lsb.max() <= 1, (fraction, lsb.max())
+        print(f"C5 band at {fraction}: geometry {float((frame.depth > 0).mean()):.2f}, max UNORM16 diff {lsb.max()} LSB")
+    # 256 lights light the scene: the lights pass alone (before the composite) is far from black on the geometry rows
+    assert q[int(0.7 * H)][..., :3].mean() > 0
