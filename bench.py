@@ -17,7 +17,8 @@ Workloads (BASELINE.json configs):
     c5  3840x2160, 256 spot lights per GPU, independent replicas, no collective
 
 Prints ONE JSON line on rank 0 (see the repo contract), with `roofline` for the dominant
-kernel (the composite) and `cpu_baseline` (the scalar oracle timed on this box's cores).
+kernel of the run (its longest pass) and `cpu_baseline` (the scalar oracle timed on this box's
+cores: all threads, and one thread). `python bench.py --gpus N` without a launcher starts its own N ranks.
 """
 import argparse
 import ctypes as C
@@ -65,7 +66,8 @@ def main():
                     help="nccl = RCCL over xGMI (the product); gloo = host-staged rehearsal of the N-rank path")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal: every rank renders on cuda:0 (several ranks on a one-GPU box; needs --backend gloo)")
-    ap.add_argument("--cpu-rows", type=int, default=540, help="rows of the frame the CPU baseline shades")
+    ap.add_argument("--cpu-rows", type=int, default=540, help="rows of the frame the all-threads CPU baseline shades")
+    ap.add_argument("--no-extras", action="store_true", help="skip the measurements that are not part of `value` (profiling runs)")
     args = ap.parse_args()
 
     # The contract is ONE JSON line on stdout. Libraries write there too (RCCL prints its version banner to stdout on
@@ -92,12 +94,11 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1 or args.force_tiled:
+        # Control plane (rendezvous, barrier, the max-over-ranks reduction of the wall time): gloo over 127.0.0.1.
+        # Data plane with --backend nccl: RCCL behind the C-ABI (rowtile.Comm = szg_rowtile_comm, include/szg/abi.h).
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import __graft_entry__ as entry
 
@@ -152,7 +153,8 @@ def main():
         gathered = [torch.empty((nranks, stride_rows, W, 4), dtype=torch.int16, device=dev) for _ in range(2)]
         composed = torch.empty((H, W, 4), dtype=torch.int16, device=dev)
 
-    sky_lut = sky.skyviewLUT_tensor() if tiled else None
+    comm = rowtile.Comm(rank, world, local_rank) if ((world > 1 or args.force_tiled) and args.backend == "nccl") else None
+    sky_lut = sky.skyviewLUT_tensor() if (tiled and comm is None) else None
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
     spot_arg = spots if SPOTS else None
     pending = []  # (gathered buffer, work) of the previous frame's tile gather
@@ -185,9 +187,13 @@ def main():
             # LUTs first: every rank computes 1/N of the sky-view LUT rows, and the all-gather of the slices runs
             # while the lights pass (which needs no LUT) is shading
             sky.recordTransmittance(None, 0, atmospheres)
-            b, en = rowtile.lut_rows(sky_lut.shape[0], rank, nranks)
+            b, en = sky.lutRowSlice(rank, nranks)
             sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, b, en)
-            lut_work = rowtile.allgather_lut(sky_lut, rank, nranks, async_op=True, force=True)
+            if comm is not None:
+                lut_work = comm.allgather_skyview_lut(sky)
+            else:
+                lut_work = rowtile.allgather_lut(sky_lut, rank, nranks, async_op=True, force=True)
+                sky.invalidateLUTs(abi.SZG_LUT_SKYVIEW)  # texels written through the aliased tensor
             if e:
                 e[1].record()
                 e[2].record()
@@ -215,8 +221,11 @@ def main():
             if rank == 0 and gathered[k % 2].data_ptr() in compose_done:
                 # this gather buffer was last read by the compose of frame k-2 on the side stream
                 torch.cuda.current_stream().wait_event(compose_done[gathered[k % 2].data_ptr()])
-            buf, work = rowtile.gather_tiles(tgt.color, rank, nranks, gathered=gathered[k % 2] if rank == 0 else None,
-                                             async_op=True)
+            if comm is not None:
+                buf, work = comm.gather_tiles(tgt.color, gathered=gathered[k % 2] if rank == 0 else None, dst=0)
+            else:
+                buf, work = rowtile.gather_tiles(tgt.color, rank, nranks, gathered=gathered[k % 2] if rank == 0 else None,
+                                                 async_op=True)
             pending.append((buf, work))
         if e:
             e[5].record()
@@ -238,9 +247,8 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
 
-    red_dev = dev if args.backend == "nccl" else "cpu"
-    t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-    g = torch.tensor([geometry_px_local], dtype=torch.int64, device=red_dev)
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    g = torch.tensor([geometry_px_local], dtype=torch.int64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         if tiled:
@@ -264,40 +272,52 @@ def main():
     bytes_composite = 60 * N_local + 8 * G_local
     bytes_lights = 56 * N_local
     bytes_luts = 16 * (512 * 128 + 2048 * 1024)
-    comp_s = per["composite"] / 1e3
-    roofline = {
-        "bound": "hbm", "kernel": "k_composite",
-        "achieved": bytes_composite / comp_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": bytes_composite / comp_s / 1e9 / HBM_PEAK_GBS,
-        "traffic": None,
-        "algorithmic_bytes_per_launch": bytes_composite, "avg_launch_ms": per["composite"],
+    # `roofline` describes the DOMINANT kernel of THIS run: the longest pass by its mean launch time, measured with events
+    # on the launch stream inside the timed region. Algorithmic bytes per launch: SURVEY 8d / DESIGN.md 4.
+    sky_texels = sky.desc.skyview_width * sky.desc.skyview_height
+    candidates = {
+        "k_composite": (per["composite"], bytes_composite, "60 B/px + 8 B per geometry px"),
+        "k_lights": (per[names[2] if tiled else "lights"], bytes_lights, "56 B/px (48 G-buffer read + 8 colour written, clear fused)"),
     }
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_composite.json")
-    if os.path.exists(pmc) and name == "c3":
-        try:
-            roofline["traffic"] = json.load(open(pmc))["hbm_bytes_per_launch"]
-        except Exception:
-            pass
-    # What actually bounds the kernel: VALU issue. Instruction count per launch from the committed PMC
-    # profile, issue ceiling from the committed micro-benchmark; informational, the contract's `roofline` stays HBM.
+    if not tiled:
+        candidates["k_skyview"] = (per["skyview"], 16 * sky_texels, "16 B per LUT texel written")
+    dominant = max(candidates, key=lambda k: candidates[k][0])
+    dom_ms, dom_bytes, dom_rule = candidates[dominant]
+    dom_s = dom_ms / 1e3
+    roofline = {
+        "bound": "hbm", "kernel": dominant,
+        "achieved": dom_bytes / dom_s / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": dom_bytes / dom_s / 1e9 / HBM_PEAK_GBS,
+        "traffic": None,
+        "algorithmic_bytes_per_launch": dom_bytes, "algorithmic_bytes_rule": dom_rule, "avg_launch_ms": dom_ms,
+    }
+    # HBM traffic and the VALU picture come from counters, which cannot be read inside this run: they are taken from the
+    # committed profile of THIS workload (tools/collect_pmc.py: rocprofv3, separate --pmc passes, gfx950 FETCH_SIZE
+    # correction) and only when that file names this workload and this kernel.
     roofline_valu = None
-    if os.path.exists(pmc) and name == "c3":
+    pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{name}.json")
+    if os.path.exists(pmc_path) and not tiled:
         try:
-            v = json.load(open(pmc))["valu"]
-            achieved = v["SQ_INSTS_VALU_per_launch"] / comp_s / 1e9
-            peak = v["simds"] * v["clock_GHz"] / v["measured_issue_ceiling_cycles_per_instruction"]
-            roofline_valu = {"bound": "valu-issue", "kernel": "k_composite", "achieved": achieved, "peak": peak,
-                             "unit": "G wave64-instructions/s", "frac": achieved / peak,
-                             "instructions_per_launch": v["SQ_INSTS_VALU_per_launch"], "source": "profiles/r01_pmc_composite.json"}
-            if "instruction_classes_per_launch" in v:
-                # the same bound with every instruction class priced at its own measured issue cost (transcendentals 8.5
-                # cycles, min/max/select/floor 4.4, ...) instead of the 3.1 cycles of a pure fma stream
-                cycles = sum(n * v["class_issue_cycles"][c] for c, n in v["instruction_classes_per_launch"].items())
-                floor_s = cycles / (v["simds"] * v["clock_GHz"] * 1e9)
-                roofline_valu["mix_weighted_floor_ms"] = floor_s * 1e3
-                roofline_valu["frac_of_mix_weighted_ceiling"] = floor_s / comp_s
-        except Exception:
-            pass
+            prof = json.load(open(pmc_path))
+            k = prof["kernels"].get(dominant) if prof.get("workload") == name else None
+            if k is not None:
+                roofline["traffic"] = k.get("hbm_bytes_per_launch")
+                roofline["traffic_source"] = f"profiles/r02_pmc_{name}.json"
+                if "valu_issue_cycles_per_launch" in k:
+                    # every VALU instruction class priced at its issue cost measured by tools/opcost.hip
+                    # (profiles/r02_opcost.txt): what the kernel needs of the 1024 SIMDs if it did nothing but issue
+                    cyc = k["valu_issue_cycles_per_launch"]
+                    simds = 1024
+                    roofline_valu = {
+                        "bound": "valu-issue", "kernel": dominant, "unit": "SIMD-cycles per launch",
+                        "instructions_per_launch": k.get("SQ_INSTS_VALU"), "issue_cycles_per_launch": cyc,
+                        "class_costs": prof.get("class_issue_cycles"),
+                        "clock_GHz_at_which_issue_alone_takes_the_measured_time": cyc / simds / dom_s / 1e9,
+                        "frac_of_issue_ceiling_at_2.4GHz": cyc / simds / 2.4e9 / dom_s,
+                        "source": f"profiles/r02_pmc_{name}.json + profiles/r02_opcost.txt",
+                    }
+        except Exception as e:  # a malformed profile must not cost the bench line
+            log("profile not usable:", e)
     frame_bytes = bytes_composite + bytes_lights + bytes_luts
     frame_s = sum(per[n] for n in names[:4]) / 1e3
     if tiled:
@@ -312,7 +332,8 @@ def main():
         "config": {"workload": wl["label"], "width": W, "height": H, "spot_lights": SPOTS, "geometry_fraction": G_frame / (W * H),
                    "sun_elevation_deg": args.elevation, "row_tile_block_rows": BLOCK_ROWS if tiled else None,
                    "parallelism": (f"rowtile{nranks}+gather" if tiled else ("single" if world == 1 else f"replicas{world}")),
-                   "collectives": (args.backend if (world > 1 or args.force_tiled) else None)},
+                   "collectives": (args.backend if (world > 1 or args.force_tiled) else None),
+                   "rccl_ranks": (comm.size() if comm is not None else None)},
         "pass_ms_rank0": per,
         "roofline": roofline,
         "roofline_valu": roofline_valu,
@@ -336,13 +357,35 @@ def main():
 
     # Checksum of the final RGBA16 image (rank 0: the composed frame when tiled), outside the timed region: equal for
     # every N and for the untiled run of the same workload — the row-tiled path changes no pixel.
-    if rank == 0:
-        final = composed if tiled else targets[(args.steps - 1) % len(targets)].color[:H]
+    def checksum(final):
         img = final.view(torch.int16).to(torch.int64) & 0xFFFF
         weights = (torch.arange(H, device=img.device, dtype=torch.int64) % 251 + 1).view(H, 1, 1)
-        out["image_checksum"] = {"sum": int(img.sum().item()), "row_weighted_sum": int((img * weights).sum().item())}
+        return {"sum": int(img.sum().item()), "row_weighted_sum": int((img * weights).sum().item())}
 
-    if world == 1 and not tiled:
+    if rank == 0:
+        out["image_checksum"] = checksum(composed if tiled else targets[(args.steps - 1) % len(targets)].color[:H])
+
+    extras = world == 1 and not tiled and not args.no_extras
+    if extras:
+        # LUT reuse across frames (abi.h szg_skyview_set_lut_reuse; SURVEY 8e: identical results): the steady state of a
+        # scene whose atmosphere, sun and camera do not move. NOT part of `value` - the reference recomputes both LUTs every
+        # frame and so does the timed region above.
+        sky.setLUTReuse(True)
+        for k in range(2):
+            frame(k)
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        for k in range(args.steps):
+            frame(k)
+        torch.cuda.synchronize()
+        cached = (time.perf_counter() - c0) / args.steps
+        sky.setLUTReuse(False)
+        out["steady_state_cached_luts"] = {"in_value": False, "ms_per_frame": cached * 1e3, "mpixels_per_s": W * H / cached / 1e6,
+                                           "same_image": checksum(targets[(args.steps - 1) % len(targets)].color[:H]) == out["image_checksum"],
+                                           "note": "both LUT passes skipped on the device while their parameter blocks are bit-equal to "
+                                                   "those the texels were computed from; same image"}
+
+    if extras:
         # The pass right after the path, measured on its own outside the timed region: in-place
         # OETF of the final image, 16 B/px. Not part of `value`.
         # Rotate over enough distinct images (> 256 MiB together) that no pass finds its image in the Infinity Cache.
@@ -367,7 +410,7 @@ def main():
                             "frac_of_8TBps": 16 * W * H / (oetf_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "in_value": False,
                             "note": "65536-entry transfer table; images rotated so that every pass streams from HBM"}
 
-    if world == 1 and not tiled:
+    if extras:
         # Extension without a reference counterpart (abi.h "Aerial-perspective froxel LUT"): APPROXIMATE composite that
         # replaces the inline per-pixel march by a froxel-LUT fetch. Reported separately, never part of `value`.
         reps = 10
@@ -405,7 +448,7 @@ def main():
             "achieved_GBps": bytes_composite / (fast_ms / 1e3) / 1e9, "frac_of_8TBps": bytes_composite / (fast_ms / 1e3) / 1e9 / HBM_PEAK_GBS,
             "frame_ms_with_fast_mode": per["lights"] + per["transmittance"] + per["skyview"] + aerial_ms + fast_ms}
 
-    if world == 1 and not tiled:
+    if extras:
         # The pass right before the path: the G-buffer raster of the same scene given as real meshes
         # (instanced cubes + ground quad) into a second target. Producer of the path's inputs: never part of `value`.
         from syzygy_amd import meshes as mesh_lib
@@ -508,12 +551,38 @@ def cpu_baseline(args, wl, atm, cam, sun, moon, spots, syn):
     t4 = time.perf_counter()
     scale = H / tile.local_rows
     est = (t1 - t0) + (t2 - t1) + ((t3 - t2) + (t4 - t3)) * scale
+
+    # (i) of BASELINE.md: the same restatement on ONE thread, on a smaller sample of the same frame: a quarter of the
+    # transmittance LUT's texels (a 256 x 64 LUT: config 1's own size), 8 sky-view LUT rows above and 8 below the horizon,
+    # lights + composite on 24 rows spread evenly over the frame.
+    s0 = time.perf_counter()
+    ob.transmittance_lut(atm, 256, 64, threads=1)
+    s1 = time.perf_counter()
+    scratch = np.zeros((1024, 2048, 4), np.float32)
+    ob.skyview_lut(atm, cam, tlut, 2048, 1024, row_begin=252, row_end=260, threads=1, out=scratch)
+    ob.skyview_lut(atm, cam, tlut, 2048, 1024, row_begin=764, row_end=772, threads=1, out=scratch)
+    s2 = time.perf_counter()
+    n1 = H // 24
+    tile1 = abi.RowTile(1, n1 // 2, n1, lib().szg_rowtile_local_rows(H, 1, n1 // 2, n1))
+    frame1 = ob.HostFrame(W, tile1.local_rows, debug=False)
+    ob.gbuffer_fill(frame1, rect, tile1, cam, syn.fill, threads=threads)
+    s3 = time.perf_counter()
+    ob.lights(frame1, rect, tile1, None, cam, dirs, 2, 1, spots, SPOTS, threads=1)
+    s4 = time.perf_counter()
+    ob.composite(frame1, rect, tile1, None, atm, cam, dirs, 0, tlut, slut, threads=1)
+    s5 = time.perf_counter()
+    est1 = (s1 - s0) * 4.0 + (s2 - s1) * (1024 / 16) + ((s4 - s3) + (s5 - s4)) * (H / tile1.local_rows)
     return {
         "value": W * H / est / 1e6, "unit": "Mpixels/s", "cores": threads, "kind": "port",
         "sample": (f"both LUTs in full ({t1 - t0:.2f}s + {t2 - t1:.2f}s) + lights/composite on {tile.local_rows} of {H} rows "
                    f"spread evenly over the frame ({t3 - t2:.2f}s + {t4 - t3:.2f}s), extrapolated x{scale:.1f}; "
                    f"{threads} std::threads, -O2 -ffp-contract=off"),
         "estimated_frame_s": est,
+        "single_thread": {
+            "value": W * H / est1 / 1e6, "unit": "Mpixels/s", "cores": 1, "kind": "port", "estimated_frame_s": est1,
+            "sample": (f"transmittance LUT 256x64 ({s1 - s0:.2f}s, x4 texels), 16 of 1024 sky-view LUT rows ({s2 - s1:.2f}s), "
+                       f"lights/composite on {tile1.local_rows} of {H} rows ({s4 - s3:.2f}s + {s5 - s4:.2f}s); one thread"),
+        },
     }
 
 

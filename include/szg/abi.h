@@ -185,8 +185,11 @@ typedef struct szg_image
     uint32_t format;      /* szg_format */
 } szg_image;
 
-/* VkRect2D of the reference API. The reference ignores the offset (lights.comp
- * gbufferOffset is always 0: deferred.cpp:764; camera.comp has none), so do we. */
+/* VkRect2D of the reference API. The reference dispatches every pass over the extent only and pushes
+ * gbufferOffset = 0 (lights.comp:112 with deferred.cpp:764, :778-787; camera.comp has no offset at all,
+ * skyview.cpp:658-665): whatever the offset says, it shades the top-left width x height texels. A non-zero x or y
+ * is therefore a request this path does not serve: every record_* entry point refuses it with
+ * SZG_ERR_INVALID_ARGUMENT instead of silently rendering somewhere else. */
 typedef struct szg_rect
 {
     int32_t x, y;
@@ -284,10 +287,7 @@ typedef struct szg_skyview_desc
     uint32_t padding;
 } szg_skyview_desc;
 
-/* No flags are defined yet. To reuse the LUTs across frames whose atmosphere block, sun direction and camera
- * position are unchanged (the reference recomputes them every frame, skyview.cpp:799-893; results are
- * identical either way), call szg_skyview_record_composite() alone instead of
- * szg_skyview_record_draw_commands(). */
+/* No flags are defined yet. */
 
 /* skyview.hpp:36-37 `create(device, allocator)`; returns SZG_OK and *out, or a
  * negative status and *out = NULL (reference: nullptr, skyview.cpp:713-740). */
@@ -320,6 +320,13 @@ int szg_skyview_record_skyview_lut(szg_skyview_t* p, void* stream, uint32_t atmo
 int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
                                         const szg_atmosphere_packed* d_atmospheres, uint32_t view_camera_index,
                                         const szg_camera_packed* d_cameras, uint32_t row_begin, uint32_t row_end);
+/* The rows rank `rank` of `nranks` computes (an even split; the LUT height must divide), and the exchange that completes
+ * the LUT on every rank: one in-place all-gather of the slices on `stream` (szg_rowtile_allgather on the pipeline's own
+ * LUT memory). The sky-view LUT is the Amdahl term of the row-tiled frame (identical on every rank), hence this second,
+ * optional collective of SURVEY 8e. */
+struct szg_rowtile_comm;
+int szg_skyview_lut_row_slice(const szg_skyview_t* p, uint32_t rank, uint32_t nranks, uint32_t* row_begin, uint32_t* row_end);
+int szg_skyview_allgather_lut_rows(szg_skyview_t* p, struct szg_rowtile_comm* comm, void* stream);
 int szg_skyview_record_composite(szg_skyview_t* p, void* stream, const szg_scene_texture* scene_texture,
                                  szg_rect draw_rect, const szg_rowtile* tile, const szg_gbuffer* gbuffer,
                                  const szg_shadowmaps* shadow_maps, uint32_t atmosphere_index,
@@ -377,6 +384,24 @@ int szg_skyview_multiscatter_lut(const szg_skyview_t* p, szg_image* out);
  * LUT's value range, the sky-view LUT's finiteness). */
 int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out);
 int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out);
+/* The same notice without fetching the image again: the caller has written (or is about to write) texels of the LUTs named
+ * in `which` through a pointer it kept. The next consumer re-scans them, and with LUT reuse (below) the next record of that
+ * LUT recomputes it. A written transmittance LUT also invalidates the sky-view LUT, which is a function of it. */
+#define SZG_LUT_TRANSMITTANCE 1u
+#define SZG_LUT_SKYVIEW 2u
+int szg_skyview_invalidate_luts(szg_skyview_t* p, uint32_t which);
+
+/* LUT reuse across frames (no reference counterpart: the reference records both LUT dispatches every frame,
+ * skyview.cpp:799-893, although the transmittance LUT depends on the atmosphere block alone and the sky-view LUT on that
+ * block - which carries the sun direction - and the camera position; SURVEY 8e asks for it because the results are
+ * identical). Off by default. When enabled, szg_skyview_record_transmittance / _record_skyview_lut / _record_draw_commands
+ * first compare, ON THE DEVICE and in stream order, the parameter blocks they are given with the ones the current texels
+ * were computed from, bit for bit (the blocks are device memory: the host never reads them), and the LUT kernel behind the
+ * comparison returns at once when nothing changed: a frame with an unchanged atmosphere, sun and camera position costs two
+ * one-wave launches and two empty ones instead of ~1 ms. Changing any dword of the atmosphere block recomputes both LUTs,
+ * moving the camera recomputes the sky-view LUT. Texels written by the caller (the accessors above,
+ * szg_skyview_invalidate_luts) and row-slice launches are always followed by a recompute. */
+int szg_skyview_set_lut_reuse(szg_skyview_t* p, int enable);
 
 /* ------------------------------------------------------------------------- */
 /* DeferredShadingPipeline (renderer/pipelines/deferred.hpp:23-119)            */
@@ -479,6 +504,32 @@ int szg_compose_rowtiles(void* stream, const void* gathered, size_t tile_stride_
 
 /* Number of local rows rank `rank` holds for a frame of `height` rows. */
 uint32_t szg_rowtile_local_rows(uint32_t height, uint32_t block_rows, uint32_t rank, uint32_t nranks);
+
+/* ------------------------------------------------------------------------- */
+/* Multi-GPU collectives (no reference counterpart; BASELINE north_star:       */
+/* "a single RCCL gather over xGMI for the composed image")                    */
+/* ------------------------------------------------------------------------- */
+/* One process per GPU. A communicator binds this process (rank r of n) to the others through RCCL, which is loaded at
+ * run time (librccl.so.1; SZG_RCCL_LIBRARY overrides the name): the library itself does not link against it. Rank 0
+ * obtains SZG_ROWTILE_COMM_ID_BYTES opaque bytes from szg_rowtile_comm_unique_id() and hands them to every rank by any
+ * means (the caller's launcher: a file, a socket, MPI, torch.distributed); every rank then calls
+ * szg_rowtile_comm_create(rank, nranks, id, device) - a collective call, like ncclCommInitRank. */
+typedef struct szg_rowtile_comm szg_rowtile_comm_t;
+#define SZG_ROWTILE_COMM_ID_BYTES 256
+int szg_rowtile_comm_unique_id(void* out_id);
+int szg_rowtile_comm_create(szg_rowtile_comm_t** out, int rank, int nranks, const void* unique_id, int device);
+void szg_rowtile_comm_destroy(szg_rowtile_comm_t* comm);
+int szg_rowtile_comm_rank(const szg_rowtile_comm_t* comm);
+int szg_rowtile_comm_size(const szg_rowtile_comm_t* comm); /* the rank count RCCL reports for the communicator */
+/* THE collective of the frame: every rank's packed row tile (`tile_bytes` bytes at `tile`, the same size on every rank:
+ * szg_rowtile stride rows x pitch) lands at gathered + rank * tile_bytes on `root`; `gathered` is ignored elsewhere.
+ * N - 1 point-to-point streams into the root (ncclGather, or grouped ncclSend / ncclRecv), enqueued on `stream`; returns
+ * immediately. Follow it with szg_compose_rowtiles() on the root. */
+int szg_rowtile_gather(szg_rowtile_comm_t* comm, void* stream, const void* tile, size_t tile_bytes, void* gathered, int root);
+/* In-place all-gather: rank r has filled bytes [r * bytes_per_rank, (r + 1) * bytes_per_rank) of `buffer` (the same
+ * layout on every rank); afterwards every rank holds all of it. Uses a communicator of its own, so it may be in flight
+ * (on another stream) while a gather is. */
+int szg_rowtile_allgather(szg_rowtile_comm_t* comm, void* stream, void* buffer, size_t bytes_per_rank);
 
 /* ------------------------------------------------------------------------- */
 /* Host input prep (CPU only; renderer/scene.cpp, renderer/lights.cpp,         */

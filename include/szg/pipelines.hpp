@@ -38,8 +38,13 @@ using DirectionalLightPacked = szg_directional_light_packed;
 using SpotLightPacked = szg_spot_light_packed;
 
 // buffers.hpp:209-299 — host staging + device copy, recordCopyToDevice on a stream.
+// recordCopyToDevice is asynchronous: the copy runs in stream order, possibly behind a whole frame of kernels, while the
+// caller goes on to stage the next frame. The reference guards its staging memory with the frame fences (two frames in
+// flight, framebuffer.cpp:134); here the staged bytes are handed to the stream through a small ring of pinned slots, and a
+// slot is rewritten only after the event recorded behind its last copy has completed.
 template <typename T> struct TStagedBuffer
 {
+    static constexpr int RING_SLOTS = 3;
     TStagedBuffer() = default;
     TStagedBuffer(TStagedBuffer const&) = delete;
     auto operator=(TStagedBuffer const&) -> TStagedBuffer& = delete;
@@ -53,6 +58,16 @@ template <typename T> struct TStagedBuffer
         m_staged = o.m_staged;
         m_deviceSize = o.m_deviceSize;
         m_dirty = o.m_dirty;
+        m_next = o.m_next;
+        for (int i = 0; i < RING_SLOTS; i++)
+        {
+            m_ring[i] = o.m_ring[i];
+            m_done[i] = o.m_done[i];
+            m_used[i] = o.m_used[i];
+            o.m_ring[i] = nullptr;
+            o.m_done[i] = nullptr;
+            o.m_used[i] = false;
+        }
         o.m_host = nullptr;
         o.m_device = nullptr;
         o.m_capacity = 0;
@@ -63,8 +78,14 @@ template <typename T> struct TStagedBuffer
     static auto allocate(size_t capacity) -> TStagedBuffer<T>
     {
         TStagedBuffer<T> b;
-        if (hipHostMalloc(reinterpret_cast<void**>(&b.m_host), capacity * sizeof(T), hipHostMallocDefault) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void**>(&b.m_device), capacity * sizeof(T)) != hipSuccess)
+        bool ok = hipHostMalloc(reinterpret_cast<void**>(&b.m_host), capacity * sizeof(T), hipHostMallocDefault) == hipSuccess &&
+                  hipMalloc(reinterpret_cast<void**>(&b.m_device), capacity * sizeof(T)) == hipSuccess;
+        for (int i = 0; ok && i < RING_SLOTS; i++)
+        {
+            ok = hipHostMalloc(reinterpret_cast<void**>(&b.m_ring[i]), capacity * sizeof(T), hipHostMallocDefault) == hipSuccess &&
+                 hipEventCreateWithFlags(&b.m_done[i], hipEventDisableTiming) == hipSuccess;
+        }
+        if (!ok)
         {
             std::fprintf(stderr, "[szg] TStagedBuffer::allocate(%zu) failed\n", capacity);
             b.destroy();
@@ -100,7 +121,16 @@ template <typename T> struct TStagedBuffer
     {
         if (m_staged > 0)
         {
-            (void)hipMemcpyAsync(m_device, m_host, m_staged * sizeof(T), hipMemcpyHostToDevice, cmd);
+            int const slot = m_next;
+            m_next = (m_next + 1) % RING_SLOTS;
+            if (m_used[slot])
+            {
+                (void)hipEventSynchronize(m_done[slot]); // the copy that last read this slot has run
+            }
+            std::memcpy(m_ring[slot], m_host, m_staged * sizeof(T));
+            (void)hipMemcpyAsync(m_device, m_ring[slot], m_staged * sizeof(T), hipMemcpyHostToDevice, cmd);
+            (void)hipEventRecord(m_done[slot], cmd);
+            m_used[slot] = true;
         }
         m_deviceSize = m_staged;
         m_dirty = false;
@@ -123,6 +153,24 @@ template <typename T> struct TStagedBuffer
 private:
     void destroy()
     {
+        for (int i = 0; i < RING_SLOTS; i++)
+        {
+            if (m_used[i])
+            {
+                (void)hipEventSynchronize(m_done[i]);
+            }
+            if (m_done[i] != nullptr)
+            {
+                (void)hipEventDestroy(m_done[i]);
+            }
+            if (m_ring[i] != nullptr)
+            {
+                (void)hipHostFree(m_ring[i]);
+            }
+            m_ring[i] = nullptr;
+            m_done[i] = nullptr;
+            m_used[i] = false;
+        }
         if (m_host != nullptr)
         {
             (void)hipHostFree(m_host);
@@ -137,6 +185,10 @@ private:
     }
     T* m_host{nullptr};
     T* m_device{nullptr};
+    T* m_ring[RING_SLOTS]{};
+    hipEvent_t m_done[RING_SLOTS]{};
+    bool m_used[RING_SLOTS]{};
+    int m_next{0};
     size_t m_capacity{0};
     size_t m_staged{0};
     size_t m_deviceSize{0};
@@ -284,6 +336,36 @@ struct SkyViewComputePipeline
         (void)szg_skyview_record_draw_commands(m_handle, cmd, &sceneTexture.texture(), drawRect, tile, &gbuffer, &shadowMaps,
                                                atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
                                                cameras.deviceAddress(), sunLightIndex, lights.deviceAddress());
+    }
+    // ---- extensions without a reference counterpart (szg/abi.h) ----
+    // LUT reuse across frames whose atmosphere / sun / camera position are unchanged (identical results)
+    void setLUTReuse(bool enable) { (void)szg_skyview_set_lut_reuse(m_handle, enable ? 1 : 0); }
+    void invalidateLUTs(uint32_t which = SZG_LUT_TRANSMITTANCE | SZG_LUT_SKYVIEW) { (void)szg_skyview_invalidate_luts(m_handle, which); }
+    // Row-tiled multi-GPU frame: transmittance LUT, this rank's slice of the sky-view LUT, the all-gather of the slices on
+    // `lutStream` (ordered behind `cmd` by an event), then the composite on `cmd` once the LUT is complete.
+    void recordDrawCommandsTiled(hipStream_t cmd, hipStream_t lutStream, hipEvent_t scratchEvent, szg_rowtile_comm_t* comm,
+                                 SceneTexture& sceneTexture, szg_rect drawRect, szg_gbuffer const& gbuffer,
+                                 szg_shadowmaps const& shadowMaps, uint32_t atmosphereIndex,
+                                 TStagedBuffer<AtmospherePacked> const& atmospheres, uint32_t viewCameraIndex,
+                                 TStagedBuffer<CameraPacked> const& cameras, uint32_t sunLightIndex,
+                                 TStagedBuffer<DirectionalLightPacked> const& lights, szg_rowtile const& tile)
+    {
+        uint32_t begin = 0, end = 0;
+        (void)szg_skyview_record_transmittance(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress());
+        if (szg_skyview_lut_row_slice(m_handle, tile.rank, tile.nranks, &begin, &end) != SZG_OK)
+        {
+            return;
+        }
+        (void)szg_skyview_record_skyview_lut_rows(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
+                                                  cameras.deviceAddress(), begin, end);
+        (void)hipEventRecord(scratchEvent, cmd);
+        (void)hipStreamWaitEvent(lutStream, scratchEvent, 0);
+        (void)szg_skyview_allgather_lut_rows(m_handle, comm, lutStream);
+        (void)hipEventRecord(scratchEvent, lutStream);
+        (void)hipStreamWaitEvent(cmd, scratchEvent, 0);
+        (void)szg_skyview_record_composite(m_handle, cmd, &sceneTexture.texture(), drawRect, &tile, &gbuffer, &shadowMaps,
+                                           atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex, cameras.deviceAddress(),
+                                           sunLightIndex, lights.deviceAddress());
     }
     [[nodiscard]] auto transmittanceLUT() const -> szg_image
     {

@@ -16,6 +16,9 @@ SZG_AERIAL_W = SZG_AERIAL_H = SZG_AERIAL_D = 32
 SZG_OETF_PURE_GAMMA = 0
 SZG_OETF_SRGB = 1
 
+SZG_ROWTILE_COMM_ID_BYTES = 256
+SZG_LUT_TRANSMITTANCE = 1
+SZG_LUT_SKYVIEW = 2
 SZG_FORMAT_UNDEFINED = 0
 SZG_FORMAT_RGBA16_SFLOAT = 1
 SZG_FORMAT_RGBA32_SFLOAT = 2
@@ -371,6 +374,17 @@ ABI_FUNCTIONS = {
     ),
     "szg_skyview_transmittance_lut": (C.c_int, [VP, P(Image)]),
     "szg_skyview_skyview_lut": (C.c_int, [VP, P(Image)]),
+    "szg_skyview_invalidate_luts": (C.c_int, [VP, C.c_uint32]),
+    "szg_skyview_lut_row_slice": (C.c_int, [VP, C.c_uint32, C.c_uint32, P(C.c_uint32), P(C.c_uint32)]),
+    "szg_skyview_allgather_lut_rows": (C.c_int, [VP, VP, VP]),
+    "szg_rowtile_comm_unique_id": (C.c_int, [VP]),
+    "szg_rowtile_comm_create": (C.c_int, [P(VP), C.c_int, C.c_int, VP, C.c_int]),
+    "szg_rowtile_comm_destroy": (None, [VP]),
+    "szg_rowtile_comm_rank": (C.c_int, [VP]),
+    "szg_rowtile_comm_size": (C.c_int, [VP]),
+    "szg_rowtile_gather": (C.c_int, [VP, VP, VP, C.c_size_t, VP, C.c_int]),
+    "szg_rowtile_allgather": (C.c_int, [VP, VP, VP, C.c_size_t]),
+    "szg_skyview_set_lut_reuse": (C.c_int, [VP, C.c_int]),
     "szg_deferred_create": (C.c_int, [P(VP), P(DeferredDesc), C.c_int]),
     "szg_deferred_destroy": (None, [VP]),
     "szg_deferred_record_draw_commands": (

@@ -62,8 +62,14 @@ template <bool LEAN> SZG_DEV V3 transmittanceProduct(const Atm& a, V3 origin, V3
 
 // 256-thread workgroups = 32 texels x 8 lanes. 512x128 texels -> 2048 workgroups, 8 waves per SIMD.
 __global__ __launch_bounds__(256) void k_transmittance(const szg_atmosphere_packed* __restrict__ atmospheres,
-                                                      unsigned atmosphereIndex, float4* __restrict__ lut, int W, int H)
+                                                      unsigned atmosphereIndex, float4* __restrict__ lut, int W, int H,
+                                                      const unsigned* __restrict__ dirty)
 {
+    // LUT reuse (szg_launch.hpp "LUT reuse"): k_lut_key found the inputs byte-equal to those the texels were computed from
+    if (dirty != nullptr && dirty[0] == 0u)
+    {
+        return;
+    }
     int const sub = (int)(threadIdx.x & (unsigned)(T_LANES - 1));
     int const idRaw = (int)((blockIdx.x * 256u + threadIdx.x) / (unsigned)T_LANES);
     bool const inRangeTexel = idRaw < W * H;
@@ -139,8 +145,12 @@ __global__ __launch_bounds__(256) void k_lut_range(float4* __restrict__ lut, uns
 __global__ __launch_bounds__(256, 4) void k_skyview(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
                                                  const szg_camera_packed* __restrict__ cameras, unsigned cameraIndex,
                                                  const float4* __restrict__ tlut, int tW, int tH, float4* __restrict__ lut,
-                                                 int W, int H, int rowBegin, int rowEnd)
+                                                 int W, int H, int rowBegin, int rowEnd, const unsigned* __restrict__ dirty)
 {
+    if (dirty != nullptr && dirty[0] == 0u) // LUT reuse: inputs unchanged since these texels were computed
+    {
+        return;
+    }
     unsigned const tid = threadIdx.x;
     unsigned const wave = tid >> 6, lane = tid & 63u;
     int const x = (int)(blockIdx.x * 32u + wave * 8u + (lane & 7u));
@@ -359,16 +369,86 @@ hipError_t launch_multiscatter(hipStream_t s, const szg_atmosphere_packed* d_atm
 }
 
 hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, float* lut, unsigned W,
-                                unsigned H)
+                                unsigned H, const unsigned* d_dirty)
 {
     unsigned const n = W * H * (unsigned)T_LANES;
-    hipError_t const e = hipMemsetAsync(lut + (size_t)W * H * 4u, 0, 4u, s); // status dword: set by texels out of range
-    if (e != hipSuccess)
+    if (d_dirty == nullptr) // (with LUT reuse k_lut_key clears the dword, and only when the texels are recomputed)
     {
-        return e;
+        hipError_t const e = hipMemsetAsync(lut + (size_t)W * H * 4u, 0, 4u, s); // status dword: set by texels out of range
+        if (e != hipSuccess)
+        {
+            return e;
+        }
     }
     hipLaunchKernelGGL(k_transmittance, dim3((n + 255u) / 256u), dim3(256), 0, s, d_atm, atmIndex, reinterpret_cast<float4*>(lut),
-                       (int)W, (int)H);
+                       (int)W, (int)H, d_dirty);
+    return hipGetLastError();
+}
+
+// LUT reuse across frames (szg_launch.hpp). One wave. `state` holds, as dwords: [0, 32) the atmosphere block the
+// transmittance LUT was computed from, [32, 64) the one the sky-view LUT was computed from, [64, 67) its camera position,
+// [67] the generation of the transmittance LUT, [68] the generation the sky-view LUT was computed from, [69] / [70] the
+// dirty flags the two LUT kernels read. which == 0: transmittance; which == 1: sky-view. Comparisons are on the bit
+// patterns: byte-equal inputs give byte-equal texels.
+__global__ __launch_bounds__(64) void k_lut_key(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
+                                                const szg_camera_packed* __restrict__ cameras, unsigned cameraIndex,
+                                                unsigned* __restrict__ state, unsigned which, unsigned force,
+                                                unsigned* __restrict__ statusDword)
+{
+    unsigned const lane = threadIdx.x;
+    const unsigned* const atm = reinterpret_cast<const unsigned*>(atmospheres + atmosphereIndex);
+    unsigned* const key = state + (which == 0u ? 0u : 32u);
+    bool differs = false;
+    unsigned mine = 0u;
+    if (lane < 32u)
+    {
+        mine = atm[lane];
+        differs = mine != key[lane];
+    }
+    else if (which == 1u && lane < 35u)
+    {
+        mine = reinterpret_cast<const unsigned*>((cameras + cameraIndex)->position)[lane - 32u];
+        differs = mine != state[64u + (lane - 32u)];
+    }
+    bool dirty = force != 0u || __builtin_amdgcn_ballot_w64(differs) != 0ull;
+    if (which == 1u)
+    {
+        dirty = dirty || state[67] != state[68]; // the transmittance LUT has been recomputed since
+    }
+    if (dirty)
+    {
+        if (lane < 32u)
+        {
+            key[lane] = mine;
+        }
+        else if (which == 1u && lane < 35u)
+        {
+            state[64u + (lane - 32u)] = mine;
+        }
+    }
+    if (lane == 0u)
+    {
+        if (dirty)
+        {
+            if (which == 0u)
+            {
+                state[67] = state[67] + 1u;
+            }
+            else
+            {
+                state[68] = state[67];
+            }
+            statusDword[0] = 0u; // the recomputing kernel sets it again where a texel is out of range
+        }
+        state[69u + which] = dirty ? 1u : 0u;
+    }
+}
+
+hipError_t launch_lut_key(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
+                          unsigned camIndex, unsigned* d_state, unsigned which, bool force, float* lutBlock, unsigned W, unsigned H)
+{
+    hipLaunchKernelGGL(k_lut_key, dim3(1), dim3(64), 0, s, d_atm, atmIndex, d_cam, camIndex, d_state, which, force ? 1u : 0u,
+                       reinterpret_cast<unsigned*>(lutBlock + (size_t)W * H * 4u));
     return hipGetLastError();
 }
 
@@ -398,7 +478,7 @@ hipError_t launch_slut_check(hipStream_t s, float* lut, unsigned W, unsigned H)
 
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
-                          unsigned rowBegin, unsigned rowEnd)
+                          unsigned rowBegin, unsigned rowEnd, const unsigned* d_dirty)
 {
     if (rowEnd > H)
     {
@@ -408,9 +488,10 @@ hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
     {
         return hipSuccess;
     }
-    if (rowBegin == 0u && rowEnd == H)
+    if (rowBegin == 0u && rowEnd == H && d_dirty == nullptr)
     {
-        // a whole LUT: its status dword starts clear and the kernel sets it (partial launches leave it to launch_slut_check)
+        // a whole LUT: its status dword starts clear and the kernel sets it (partial launches leave it to launch_slut_check;
+        // with LUT reuse k_lut_key clears it)
         hipError_t const e = hipMemsetAsync(lut + (size_t)W * H * 4u, 0, 4, s);
         if (e != hipSuccess)
         {
@@ -419,7 +500,7 @@ hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
     }
     dim3 const grid((W + 31u) / 32u, (rowEnd - rowBegin + 7u) / 8u);
     hipLaunchKernelGGL(k_skyview, grid, dim3(256), 0, s, d_atm, atmIndex, d_cam, camIndex, reinterpret_cast<const float4*>(tlut),
-                       (int)tW, (int)tH, reinterpret_cast<float4*>(lut), (int)W, (int)H, (int)rowBegin, (int)rowEnd);
+                       (int)tW, (int)tH, reinterpret_cast<float4*>(lut), (int)W, (int)H, (int)rowBegin, (int)rowEnd, d_dirty);
     return hipGetLastError();
 }
 } // namespace szg

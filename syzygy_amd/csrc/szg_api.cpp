@@ -230,6 +230,43 @@ int select_device(int device)
     return SZG_OK;
 }
 
+// VkRect2D offset: the reference dispatches every pass over the extent only and pushes gbufferOffset = 0
+// (deferred.cpp:764, :778-787; skyview.cpp:658-665), i.e. it renders into the top-left sub-rectangle whatever the offset
+// says. A caller passing a non-zero offset expects something this path (like the reference's) does not do: refuse it.
+bool check_rect(const szg_rect& r, const char* what)
+{
+    if (r.x != 0 || r.y != 0)
+    {
+        fail(SZG_ERR_INVALID_ARGUMENT, "%s: draw_rect offset (%d, %d) must be (0, 0): passes cover the top-left extent only", what, r.x, r.y);
+        return false;
+    }
+    return true;
+}
+
+// A pipeline lives on the device it was created on; record_* may be called while another device is current
+// (one process driving several GPUs): switch for the duration of the call and switch back.
+struct DeviceGuard
+{
+    int previous = -1;
+    bool switched = false;
+    explicit DeviceGuard(int device)
+    {
+        if (hipGetDevice(&previous) == hipSuccess && previous != device)
+        {
+            switched = hipSetDevice(device) == hipSuccess;
+        }
+    }
+    ~DeviceGuard()
+    {
+        if (switched)
+        {
+            (void)hipSetDevice(previous);
+        }
+    }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 szg_image make_image(void* data, unsigned w, unsigned h, unsigned fmt)
 {
     szg_image im;
@@ -260,6 +297,10 @@ struct szg_skyview
     // the same for the sky-view LUT's status dword (szg_launch.hpp "sky-view LUT block"): false after a partial (row-slice)
     // launch or after szg_skyview_skyview_lut() handed the texels out
     mutable bool slutStatusValid = false;
+    // LUT reuse across frames (szg_launch.hpp "LUT reuse"; off by default = the reference's recompute-every-frame)
+    bool lutReuse = false;
+    unsigned* d_lutKey = nullptr;                      // LUT_KEY_DWORDS dwords of device state
+    mutable bool forceTransmittance = true, forceSkyview = true; // the host knows the texels are stale
 };
 
 static hipError_t ensure_tlut_status(szg_skyview* p, hipStream_t s)
@@ -408,12 +449,53 @@ int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int de
     {
         e = hipMalloc(reinterpret_cast<void**>(&p->d_aerialTransmittance), aerialBytes);
     }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_lutKey), szg::LUT_KEY_DWORDS * sizeof(unsigned));
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMemset(p->d_lutKey, 0, szg::LUT_KEY_DWORDS * sizeof(unsigned));
+    }
     if (e != hipSuccess)
     {
         szg_skyview_destroy(p);
         return fail_hip(e, "szg_skyview_create: hipMalloc");
     }
     *out = p;
+    return SZG_OK;
+}
+
+int szg_skyview_set_lut_reuse(szg_skyview_t* p, int enable)
+{
+    if (p == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_set_lut_reuse: NULL argument");
+    }
+    p->lutReuse = enable != 0;
+    // whatever was computed while reuse was off has no key on the device: the first frame after a switch recomputes
+    p->forceTransmittance = true;
+    p->forceSkyview = true;
+    return SZG_OK;
+}
+
+int szg_skyview_invalidate_luts(szg_skyview_t* p, uint32_t which)
+{
+    if (p == nullptr || (which & ~(SZG_LUT_TRANSMITTANCE | SZG_LUT_SKYVIEW)) != 0u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_invalidate_luts: NULL pipeline or unknown LUT bits 0x%x", which);
+    }
+    if ((which & SZG_LUT_TRANSMITTANCE) != 0u)
+    {
+        p->tlutStatusValid = false;
+        p->forceTransmittance = true;
+        p->forceSkyview = true; // every sky-view texel is a function of the transmittance texels
+    }
+    if ((which & SZG_LUT_SKYVIEW) != 0u)
+    {
+        p->slutStatusValid = false;
+        p->forceSkyview = true;
+    }
     return SZG_OK;
 }
 
@@ -444,6 +526,10 @@ void szg_skyview_destroy(szg_skyview_t* p)
     {
         (void)hipFree(p->d_aerialTransmittance);
     }
+    if (p->d_lutKey != nullptr)
+    {
+        (void)hipFree(p->d_lutKey);
+    }
     delete p;
 }
 
@@ -455,6 +541,8 @@ int szg_skyview_transmittance_lut(const szg_skyview_t* p, szg_image* out)
     }
     *out = make_image(p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, SZG_FORMAT_RGBA32_SFLOAT);
     p->tlutStatusValid = false; // the caller may write the texels through this view
+    p->forceTransmittance = true;
+    p->forceSkyview = true;
     return SZG_OK;
 }
 
@@ -466,6 +554,7 @@ int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out)
     }
     *out = make_image(p->d_skyview, p->desc.skyview_width, p->desc.skyview_height, SZG_FORMAT_RGBA32_SFLOAT);
     p->slutStatusValid = false; // the caller may write the texels through this view (row slices gathered from other ranks)
+    p->forceSkyview = true;
     return SZG_OK;
 }
 
@@ -476,10 +565,21 @@ int szg_skyview_record_transmittance(szg_skyview_t* p, void* stream, uint32_t at
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_transmittance: NULL argument");
     }
-    SZG_HIP(szg::launch_transmittance(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, p->d_transmittance,
-                                      p->desc.transmittance_width, p->desc.transmittance_height));
+    DeviceGuard const guard(p->device);
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    const unsigned* dirty = nullptr;
+    if (p->lutReuse)
+    {
+        // the status dword of texels written behind our back must be settled before a clean verdict may keep them
+        SZG_HIP(szg::launch_lut_key(s, d_atmospheres, atmosphere_index, nullptr, 0u, p->d_lutKey, 0u, p->forceTransmittance,
+                                    p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height));
+        dirty = p->d_lutKey + 69;
+    }
+    SZG_HIP(szg::launch_transmittance(s, d_atmospheres, atmosphere_index, p->d_transmittance, p->desc.transmittance_width,
+                                      p->desc.transmittance_height, dirty));
     p->haveTransmittance = true;
     p->tlutStatusValid = true;
+    p->forceTransmittance = false;
     return SZG_OK;
 }
 
@@ -496,14 +596,63 @@ int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_skyview_lut_rows: rows [%u, %u) outside the %u-row LUT", row_begin,
                     row_end, p->desc.skyview_height);
     }
-    SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
-    SZG_HIP(szg::launch_skyview(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, d_cameras, view_camera_index,
-                                p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
-                                p->desc.skyview_width, p->desc.skyview_height, row_begin, row_end));
+    DeviceGuard const guard(p->device);
+    hipStream_t const s = static_cast<hipStream_t>(stream);
+    bool const whole = (row_begin == 0u && row_end == p->desc.skyview_height);
+    SZG_HIP(ensure_tlut_status(p, s));
+    const unsigned* dirty = nullptr;
+    if (p->lutReuse && whole)
+    {
+        SZG_HIP(szg::launch_lut_key(s, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, p->d_lutKey, 1u, p->forceSkyview,
+                                    p->d_skyview, p->desc.skyview_width, p->desc.skyview_height));
+        dirty = p->d_lutKey + 70;
+    }
+    SZG_HIP(szg::launch_skyview(s, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, p->d_transmittance,
+                                p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview, p->desc.skyview_width,
+                                p->desc.skyview_height, row_begin, row_end, dirty));
     p->haveSkyview = true;
     // a launch over all rows leaves the status dword behind the texels right; a slice does not know the other rows
-    p->slutStatusValid = (row_begin == 0u && row_end == p->desc.skyview_height);
+    p->slutStatusValid = whole;
+    p->forceSkyview = !whole; // a slice leaves the other rows to someone else: no key describes the whole LUT
     return SZG_OK;
+}
+
+int szg_skyview_lut_row_slice(const szg_skyview_t* p, uint32_t rank, uint32_t nranks, uint32_t* row_begin, uint32_t* row_end)
+{
+    if (p == nullptr || row_begin == nullptr || row_end == nullptr || nranks == 0u || rank >= nranks)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_lut_row_slice: NULL argument or rank outside [0, nranks)");
+    }
+    if (p->desc.skyview_height % nranks != 0u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_lut_row_slice: %u LUT rows do not divide over %u ranks", p->desc.skyview_height,
+                    nranks);
+    }
+    uint32_t const n = p->desc.skyview_height / nranks;
+    *row_begin = rank * n;
+    *row_end = (rank + 1u) * n;
+    return SZG_OK;
+}
+
+int szg_skyview_allgather_lut_rows(szg_skyview_t* p, szg_rowtile_comm_t* comm, void* stream)
+{
+    if (p == nullptr || comm == nullptr)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_allgather_lut_rows: NULL argument");
+    }
+    int const nranks = szg_rowtile_comm_size(comm);
+    if (nranks < 1 || p->desc.skyview_height % (uint32_t)nranks != 0u)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_allgather_lut_rows: %u LUT rows do not divide over %d ranks",
+                    p->desc.skyview_height, nranks);
+    }
+    DeviceGuard const guard(p->device);
+    size_t const slice = (size_t)(p->desc.skyview_height / (uint32_t)nranks) * p->desc.skyview_width * 16u;
+    int const rc = szg_rowtile_allgather(comm, stream, p->d_skyview, slice);
+    // texels written by other ranks: the next consumer re-scans them (status dword) and no reuse key describes them
+    p->slutStatusValid = false;
+    p->forceSkyview = true;
+    return rc;
 }
 
 int szg_skyview_record_skyview_lut(szg_skyview_t* p, void* stream, uint32_t atmosphere_index,
@@ -528,6 +677,11 @@ static int record_composite(szg_skyview_t* p, void* stream, const szg_scene_text
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_composite: NULL argument");
     }
+    if (!check_rect(draw_rect, "szg_skyview_record_composite"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    DeviceGuard const guard(p->device);
     if (draw_rect.width == 0u || draw_rect.height == 0u)
     {
         return SZG_OK; // empty extent: nothing to dispatch (computeDispatchCount(0) == 0)
@@ -602,6 +756,7 @@ int szg_skyview_record_multiscatter_lut(szg_skyview_t* p, void* stream, uint32_t
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_multiscatter_lut: NULL argument");
     }
+    DeviceGuard const guard(p->device);
     SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(szg::launch_multiscatter(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, p->d_transmittance,
                                      p->desc.transmittance_width, p->desc.transmittance_height, p->d_multiscatter,
@@ -631,6 +786,7 @@ int szg_skyview_record_aerial_lut(szg_skyview_t* p, void* stream, uint32_t atmos
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_record_aerial_lut: max_distance_mm must be in (0, 1e6)");
     }
+    DeviceGuard const guard(p->device);
     SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(szg::launch_aerial_lut(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, d_cameras, view_camera_index,
                                    p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height,
@@ -892,6 +1048,11 @@ int szg_deferred_record_gbuffer_fill(szg_deferred_t* p, void* stream, szg_rect d
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_gbuffer_fill: NULL argument");
     }
+    if (!check_rect(draw_rect, "szg_deferred_record_gbuffer_fill"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    DeviceGuard const guard(p->device);
     if (draw_rect.width == 0u || draw_rect.height == 0u)
     {
         return SZG_OK;
@@ -936,6 +1097,11 @@ int szg_deferred_record_lights(szg_deferred_t* p, void* stream, szg_rect draw_re
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_lights: NULL argument");
     }
+    if (!check_rect(draw_rect, "szg_deferred_record_lights"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    DeviceGuard const guard(p->device);
     if (directional_light_count > 0u && d_directional_lights == nullptr)
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_lights: directional lights NULL");
@@ -1009,6 +1175,7 @@ int szg_deferred_record_shadow_maps(szg_deferred_t* p, void* stream, const szg_d
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_shadow_maps: NULL argument");
     }
+    DeviceGuard const guard(p->device);
     if ((directional_light_count > 0u && d_directional_lights == nullptr) || (spot_light_count > 0u && h_spot_lights == nullptr))
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_shadow_maps: light array NULL");
@@ -1288,6 +1455,7 @@ int ensure_raster_capacity(szg_deferred* p, hipStream_t s, size_t draws, size_t 
         {
             (void)hipFree(p->d_rasterDraws);
             p->d_rasterDraws = nullptr;
+            p->rasterDrawCapacity = 0; // (a failing hipMalloc below must not leave the old capacity behind a NULL pointer)
         }
         size_t const n = draws * 2u;
         SZG_HIP(hipMalloc(reinterpret_cast<void**>(&p->d_rasterDraws), n * sizeof(szg::RasterDraw)));
@@ -1355,6 +1523,11 @@ int szg_deferred_record_gbuffer_raster(szg_deferred_t* p, void* stream, szg_rect
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_gbuffer_raster: NULL argument");
     }
+    if (!check_rect(draw_rect, "szg_deferred_record_gbuffer_raster"))
+    {
+        return SZG_ERR_INVALID_ARGUMENT;
+    }
+    DeviceGuard const guard(p->device);
     if (draw_rect.width == 0u || draw_rect.height == 0u)
     {
         return SZG_OK;
@@ -1406,6 +1579,7 @@ int szg_deferred_record_shadow_raster(szg_deferred_t* p, void* stream, const szg
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_shadow_raster: NULL argument");
     }
+    DeviceGuard const guard(p->device);
     if ((directional_light_count > 0u && d_directional_lights == nullptr) || (spot_light_count > 0u && h_spot_lights == nullptr))
     {
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_deferred_record_shadow_raster: light array NULL");

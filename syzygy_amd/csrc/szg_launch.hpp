@@ -54,8 +54,20 @@ struct TileArgs
 // it for texels written by the caller. Every kernel that takes `tlut` reads the dword behind the texels.
 inline size_t tlut_block_bytes(unsigned W, unsigned H) { return (size_t)W * H * 16u + 16u; }
 hipError_t launch_lut_range(hipStream_t s, float* lut, unsigned W, unsigned H);
+// `d_dirty` (may be nullptr): LUT reuse flag written by launch_lut_key; the kernel returns at once when it reads 0.
 hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, float* lut, unsigned W,
-                                unsigned H);
+                                unsigned H, const unsigned* d_dirty = nullptr);
+// LUT reuse across frames ("cache the LUTs across frames when atmosphere / sun / camera altitude are unchanged
+// (allowed because results are identical)"; the reference recomputes both every frame, skyview.cpp:799-893). The parameter
+// blocks live in device memory, so the comparison runs on the device, in stream order, with no host round trip: k_lut_key
+// (one wave) compares the atmosphere block (and, for the sky-view LUT, the camera position and the generation of the
+// transmittance LUT) bit for bit with what the texels were computed from, records the verdict in state[69 + which] and, when
+// dirty, stores the new key and clears the LUT's status dword. The LUT kernel launched behind it exits at once on a clean
+// verdict. LUT_KEY_DWORDS dwords of state, zeroed at creation; `force` = the host knows the texels are stale (first use,
+// texels handed out for writing, a row-slice launch, an explicit invalidate).
+constexpr unsigned LUT_KEY_DWORDS = 72u;
+hipError_t launch_lut_key(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
+                          unsigned camIndex, unsigned* d_state, unsigned which, bool force, float* lutBlock, unsigned W, unsigned H);
 // Sky-view LUT block: W*H RGBA32F texels followed by ONE status dword (16 bytes reserved): 0 when every texel's rgb is a
 // finite number of moderate size (|x| <= 2^100). The composite consults it before it leaves a sample of this LUT unevaluated
 // (the reflection term of a non-metal pixel is an exact zero only if the sample is finite). launch_skyview over all rows
@@ -65,7 +77,7 @@ inline size_t slut_block_bytes(unsigned W, unsigned H) { return (size_t)W * H * 
 hipError_t launch_slut_check(hipStream_t s, float* lut, unsigned W, unsigned H);
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
-                          unsigned rowBegin, unsigned rowEnd);
+                          unsigned rowBegin, unsigned rowEnd, const unsigned* d_dirty = nullptr);
 hipError_t launch_light_prep(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount, unsigned dirSkip,
                              const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_slots,
                              unsigned slotCount, LightRec* d_out);

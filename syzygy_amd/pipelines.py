@@ -42,7 +42,14 @@ def rect(width, height):
 
 
 class TStagedBuffer:
-    """buffers.hpp:209-299: host staging + device copy of an array of packed structs."""
+    """buffers.hpp:209-299: host staging + device copy of an array of packed structs.
+
+    recordCopyToDevice() is asynchronous: the copy runs in stream order, possibly behind a whole frame of kernels, so the
+    pinned memory it reads must stay untouched until it has run. The reference guards its staging memory with the frame
+    fences (two frames in flight, framebuffer.cpp:134); here every copy reads its own slot of a small ring of pinned
+    buffers, and a slot is rewritten only after the event recorded behind its last copy has completed."""
+
+    SLOTS = 3
 
     def __init__(self, struct_type, capacity, device="cuda:0"):
         self.struct_type = struct_type
@@ -51,7 +58,9 @@ class TStagedBuffer:
         self._device_size = 0
         self._dirty = False
         nbytes = C.sizeof(struct_type) * self.capacity
-        self._host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+        self._ring = [torch.empty(nbytes, dtype=torch.uint8).pin_memory() for _ in range(self.SLOTS)]
+        self._ring_done = [None] * self.SLOTS
+        self._ring_next = 0
         self._device = torch.zeros(nbytes, dtype=torch.uint8, device=device)
 
     @classmethod
@@ -82,10 +91,18 @@ class TStagedBuffer:
         size = C.sizeof(self.struct_type)
         if n:
             raw = b"".join(bytes(v) for v in self._staged)
-            self._host[: n * size] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+            slot = self._ring_next
+            self._ring_next = (slot + 1) % self.SLOTS
+            if self._ring_done[slot] is not None:
+                self._ring_done[slot].synchronize()  # the copy that last read this slot has run
+            host = self._ring[slot]
+            host[: n * size] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
             stream = torch.cuda.current_stream() if cmd is None else cmd
             with torch.cuda.stream(stream) if isinstance(stream, torch.cuda.Stream) else _NullCtx():
-                self._device[: n * size].copy_(self._host[: n * size], non_blocking=True)
+                self._device[: n * size].copy_(host[: n * size], non_blocking=True)
+                done = torch.cuda.Event()
+                done.record()
+            self._ring_done[slot] = done
         self._device_size = n
         self._dirty = False
 
@@ -357,6 +374,21 @@ class SkyViewComputePipeline:
         check(lib().szg_skyview_record_skyview_lut_rows(self._h, _stream_handle(cmd), int(atmosphereIndex),
                                                         C.c_void_p(atmospheres.deviceAddress()), int(viewCameraIndex),
                                                         C.c_void_p(cameras.deviceAddress()), int(rowBegin), int(rowEnd)))
+
+    def lutRowSlice(self, rank, nranks):
+        """[begin, end) rows of the sky-view LUT that `rank` of `nranks` computes (szg_skyview_lut_row_slice)."""
+        b, e = C.c_uint32(), C.c_uint32()
+        check(lib().szg_skyview_lut_row_slice(self._h, int(rank), int(nranks), C.byref(b), C.byref(e)))
+        return int(b.value), int(e.value)
+
+    def setLUTReuse(self, enable):
+        """Extension (abi.h "LUT reuse across frames"): skip a LUT pass whose parameter blocks are bit-equal to those its
+        texels were computed from; compared on the device, identical results. Off by default (the reference recomputes)."""
+        check(lib().szg_skyview_set_lut_reuse(self._h, 1 if enable else 0))
+
+    def invalidateLUTs(self, which=abi.SZG_LUT_TRANSMITTANCE | abi.SZG_LUT_SKYVIEW):
+        """The caller wrote texels of these LUTs through a pointer / tensor it kept (abi.h szg_skyview_invalidate_luts)."""
+        check(lib().szg_skyview_invalidate_luts(self._h, int(which)))
 
     def skyviewLUT_tensor(self):
         """The sky-view LUT memory the C library owns, aliased (zero copy) as a torch float32 tensor

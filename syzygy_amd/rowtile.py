@@ -8,9 +8,11 @@ bottom. A rank stores only its own rows, packed; include/szg/abi.h `szg_rowtile`
 local -> global row map the kernels use for the camera rays (camera.comp:324 uses global pixel
 coordinates and the full draw extent).
 
-One process per GPU; the gather is `torch.distributed.gather` (RCCL over xGMI when the backend
-is "nccl", plain TCP with "gloo"): N-1 point-to-point streams into rank 0, then one HBM-bound
-row scatter (`szg_compose_rowtiles`) on rank 0.
+One process per GPU. The product's collectives are the C-ABI's (`Comm` below = szg_rowtile_comm of
+include/szg/abi.h: RCCL over xGMI, N-1 point-to-point streams into rank 0 for the tile gather and an in-place
+all-gather for the sky-view LUT slices), followed by one HBM-bound row scatter (`szg_compose_rowtiles`) on
+rank 0. The functions gather_tiles / allgather_lut do the same through torch.distributed and exist for the gloo
+rehearsals (CPU tests; several ranks sharing one GPU, where RCCL refuses to run).
 """
 import ctypes as C
 
@@ -48,6 +50,74 @@ def global_rows(height, rank, nranks, block_rows=DEFAULT_BLOCK_ROWS):
     nblocks = (height + block_rows - 1) // block_rows
     out = [np.arange(b * block_rows, min(height, (b + 1) * block_rows), dtype=np.int64) for b in range(rank, nblocks, nranks)]
     return np.concatenate(out) if out else np.zeros((0,), np.int64)
+
+
+class _EventWork:
+    """Work handle of a collective enqueued on a side stream: wait() makes the CURRENT stream wait for it (the host
+    never blocks), like torch.distributed's Work.wait() for RCCL."""
+
+    def __init__(self, event):
+        self.event = event
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.event)
+        return True
+
+
+class Comm:
+    """szg_rowtile_comm (abi.h "Multi-GPU collectives"): this rank's RCCL communicators behind the C-ABI. Creating it is
+    a collective call. The opaque id travels from rank 0 to the others through torch.distributed's object broadcast on
+    `bootstrap_group` (any backend: the control plane may be gloo); a C++ caller would use its own launcher for that.
+    The two collectives run on two side streams of their own, ordered against the compute stream by events."""
+
+    def __init__(self, rank, nranks, device_index=0, bootstrap_group=None):
+        self.rank, self.nranks = int(rank), int(nranks)
+        blob = C.create_string_buffer(abi.SZG_ROWTILE_COMM_ID_BYTES)
+        if self.rank == 0:
+            check(lib().szg_rowtile_comm_unique_id(blob))
+        if self.nranks > 1:
+            box = [bytes(blob.raw)]
+            dist.broadcast_object_list(box, src=0, group=bootstrap_group)
+            blob = C.create_string_buffer(box[0], abi.SZG_ROWTILE_COMM_ID_BYTES)
+        handle = C.c_void_p()
+        check(lib().szg_rowtile_comm_create(C.byref(handle), self.rank, self.nranks, blob, int(device_index)))
+        self._h = handle
+        self.device = torch.device("cuda", int(device_index))
+        self.tile_stream = torch.cuda.Stream(self.device)
+        self.lut_stream = torch.cuda.Stream(self.device)
+
+    def size(self):
+        """The rank count RCCL itself reports for the communicator."""
+        return int(lib().szg_rowtile_comm_size(self._h))
+
+    def destroy(self):
+        if self._h is not None:
+            lib().szg_rowtile_comm_destroy(self._h)
+            self._h = None
+
+    def gather_tiles(self, local_color, gathered=None, dst=0):
+        """THE collective of the frame (szg_rowtile_gather). `local_color`: [stride_rows, W, 4] int16 on every rank;
+        `gathered`: [nranks, stride_rows, W, 4] on `dst` (allocated if None). Returns (gathered or None, work): wait()
+        before reading `gathered` or overwriting `local_color`."""
+        assert local_color.is_cuda and local_color.is_contiguous()
+        if self.rank == dst and gathered is None:
+            gathered = torch.empty((self.nranks,) + tuple(local_color.shape), dtype=local_color.dtype, device=local_color.device)
+        self.tile_stream.wait_stream(torch.cuda.current_stream())  # the tile was rendered on the compute stream
+        nbytes = local_color.numel() * local_color.element_size()
+        check(lib().szg_rowtile_gather(self._h, C.c_void_p(self.tile_stream.cuda_stream), C.c_void_p(local_color.data_ptr()), nbytes,
+                                       C.c_void_p(gathered.data_ptr()) if self.rank == dst else None, int(dst)))
+        done = torch.cuda.Event()
+        done.record(self.tile_stream)
+        return (gathered if self.rank == dst else None), _EventWork(done)
+
+    def allgather_skyview_lut(self, sky):
+        """The optional second collective (szg_skyview_allgather_lut_rows): every rank has recorded its row slice
+        (sky.lutRowSlice) on the current stream; exchange the slices in place in the pipeline's own LUT memory."""
+        self.lut_stream.wait_stream(torch.cuda.current_stream())
+        check(lib().szg_skyview_allgather_lut_rows(sky._h, self._h, C.c_void_p(self.lut_stream.cuda_stream)))
+        done = torch.cuda.Event()
+        done.record(self.lut_stream)
+        return _EventWork(done)
 
 
 class _Done:

@@ -166,7 +166,7 @@ int main(int argc, char** argv)
 {
     if (argc < 4)
     {
-        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes | gltf <file> [loader flags] | scene [ticks]]\n");
+        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes | tiled | gltf <file> [loader flags] | scene [ticks]]\n");
         return 2;
     }
     uint32_t const W = (uint32_t)std::atoi(argv[2]), H = (uint32_t)std::atoi(argv[3]);
@@ -176,6 +176,9 @@ int main(int argc, char** argv)
     }
     bool const gltf = argc > 5 && std::strcmp(argv[4], "gltf") == 0;
     bool const realMeshes = gltf || (argc > 4 && std::strcmp(argv[4], "meshes") == 0);
+    // "tiled": the row-tiled multi-GPU frame as ONE rank of a world of one - the C-ABI's communicator (RCCL), the LUT row
+    // slice + all-gather, the tile gather to the root and the compose kernel, all from C++ (no Python, no torch)
+    bool const tiled = argc > 4 && std::strcmp(argv[4], "tiled") == 0;
 
     // scene -> packed blocks (renderer.cpp:302-342)
     szg_camera camera;
@@ -291,11 +294,54 @@ int main(int argc, char** argv)
         deferred.recordDrawCommands(cmd, sceneSubregion, *sceneTexture, 1, lights, spotlights, 0, cameras,
                                     std::span<szg_mesh_instanced const>{scene.meshes});
     }
+    else if (tiled)
+    {
+        unsigned char id[SZG_ROWTILE_COMM_ID_BYTES];
+        szg_rowtile_comm_t* comm = nullptr;
+        if (szg_rowtile_comm_unique_id(id) != SZG_OK || szg_rowtile_comm_create(&comm, 0, 1, id, 0) != SZG_OK)
+        {
+            std::fprintf(stderr, "communicator: %s\n", szg_last_error());
+            return 1;
+        }
+        szg_rowtile const tile{8u, 0u, 1u, szg_rowtile_local_rows(H, 8u, 0u, 1u)};
+        hipStream_t side = nullptr;
+        hipEvent_t ev = nullptr;
+        (void)hipStreamCreate(&side);
+        (void)hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+        deferred.recordDrawCommands(cmd, sceneSubregion, *sceneTexture, 1, lights, spotlights, 0, cameras, &geometry, &tile);
+        skyView->recordDrawCommandsTiled(cmd, side, ev, comm, *sceneTexture, sceneSubregion, deferred.gbuffer(), deferred.shadowMaps(), 0,
+                                         atmospheres, 0, cameras, 0, lights, tile);
+        // THE collective: every rank's packed rows to rank 0, then the row scatter into the frame
+        size_t const tileBytes = (size_t)sceneTexture->color().pitch_bytes * tile.local_rows;
+        void *gathered = nullptr, *composed = nullptr;
+        (void)hipMalloc(&gathered, tileBytes);
+        (void)hipMalloc(&composed, (size_t)W * H * 8);
+        szg_image const frame{composed, W, H, W * 8u, SZG_FORMAT_RGBA16_UNORM};
+        int rc = szg_rowtile_gather(comm, cmd, sceneTexture->color().data, tileBytes, gathered, 0);
+        if (rc == SZG_OK)
+        {
+            rc = szg_compose_rowtiles(cmd, gathered, tileBytes, 1u, tile.block_rows, &frame, W, H);
+        }
+        if (rc != SZG_OK || hipStreamSynchronize(cmd) != hipSuccess)
+        {
+            std::fprintf(stderr, "tiled frame: %s\n", szg_last_error());
+            return 1;
+        }
+        std::printf("ranks %d\n", szg_rowtile_comm_size(comm));
+        (void)hipMemcpy2DAsync(sceneTexture->color().data, sceneTexture->color().pitch_bytes, composed, (size_t)W * 8, (size_t)W * 8, H,
+                               hipMemcpyDeviceToDevice, cmd);
+        (void)hipStreamSynchronize(cmd);
+        szg_rowtile_comm_destroy(comm);
+        (void)hipFree(gathered);
+        (void)hipFree(composed);
+        (void)hipEventDestroy(ev);
+        (void)hipStreamDestroy(side);
+    }
     else
     {
         deferred.recordDrawCommands(cmd, sceneSubregion, *sceneTexture, 1, lights, spotlights, 0, cameras, &geometry);
     }
-    if (!gltf)
+    if (!gltf && !tiled)
     {
         skyView->recordDrawCommands(cmd, *sceneTexture, sceneSubregion, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0,
                                     cameras, 0, lights);

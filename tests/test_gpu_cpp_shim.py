@@ -251,3 +251,21 @@ def test_cpp_engine_frame_scene_and_renderer_match_oracle(tmp_path):
     ob.composite(frame, rect, None, host_maps, atm, cam, dirs, 0, tl, sl, threads=8)
     assert (frame.depth > 0).mean() > 0.3
     assert np.abs(got.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+
+
+def test_cpp_tiled_frame_through_the_c_abi_collectives(tmp_path):
+    """tests/cpp/record_draw.cpp `tiled`: a C++ caller (no Python, no torch) renders the row-tiled frame as the one rank of a
+    world of one - szg_rowtile_comm over RCCL, the sky-view LUT row slice + in-place all-gather, the tile gather to the root,
+    the compose kernel - and must produce the plain frame bit for bit."""
+    exe = os.path.join(HERE, "cpp", "record_draw")
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpp"), "record_draw"], check=True)
+    W, H = 200, 120
+    plain, tiled = tmp_path / "plain.bin", tmp_path / "tiled.bin"
+    r = subprocess.run([exe, str(plain), str(W), str(H)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([exe, str(tiled), str(W), str(H), "tiled"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr + r.stdout
+    assert "ranks 1" in r.stdout
+    a = np.fromfile(plain, dtype=np.uint16)
+    b = np.fromfile(tiled, dtype=np.uint16)
+    assert a.shape == b.shape and (a == b).all()

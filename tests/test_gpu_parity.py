@@ -1059,3 +1059,169 @@ def test_c5_full_size_frame_chain(gpu):
         print(f"C5 band at {fraction}: geometry {float((frame.depth > 0).mean()):.2f}, max UNORM16 diff {lsb.max()} LSB")
     # 256 lights light the scene: the lights pass alone (before the composite) is far from black on the geometry rows
     assert q[int(0.7 * H)][..., :3].mean() > 0
+
+
+# ---------------------------------------------------------------------------
+# round 2: LUT reuse, explicit invalidation, draw-rect offsets, staging ring, C-ABI collectives
+# ---------------------------------------------------------------------------
+def _frame_with(gpu, sky, deferred, target, inp, staged_buffers):
+    cameras, atmospheres, lights = staged_buffers
+    deferred.recordDrawCommands(None, inp.rect, target, 1, lights, inp.spots if inp.spot_count else None, 0, cameras, inp.synthetic.fill)
+    sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    return target.color_numpy().copy(), sky.download_lut(sky.transmittanceLUT()).copy(), sky.download_lut(sky.skyviewLUT()).copy()
+
+
+def test_lut_reuse_gives_identical_frames_and_tracks_every_input(gpu):
+    """szg_skyview_set_lut_reuse: frames with reuse == frames without, bit for bit, over a sequence in which
+    nothing changes, then the sun moves (atmosphere block), then only the camera moves (sky-view LUT alone), then the caller
+    overwrites LUT texels behind the pipeline's back and says so (szg_skyview_invalidate_luts)."""
+    W, H = 160, 96
+    lut = dict(transmittance_extent=(128, 32), skyview_extent=(256, 128))
+    from syzygy_amd import scene
+
+    def inputs(elevation, height):
+        cam = scene.default_camera()
+        cam.cameraPosition[1] = -height
+        return util.Inputs(W, H, elevation_degrees=elevation, spots=2, camera=cam)
+
+    sequence = [inputs(35.0, 10.0), inputs(35.0, 10.0), inputs(35.0, 10.0), inputs(12.0, 10.0), inputs(12.0, 10.0),
+                inputs(12.0, 900.0), inputs(12.0, 900.0)]
+    results = {}
+    for reuse in (False, True):
+        sky = gpu.pl.SkyViewComputePipeline.create(**lut)
+        alias = sky.skyviewLUT_tensor()  # a pointer the caller keeps for later
+        sky.setLUTReuse(reuse)
+        deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=2, max_shadow_maps=0)
+        target = gpu.pl.SceneTexture(W, H)
+        frames = []
+        for inp in sequence:
+            frames.append(_frame_with(gpu, sky, deferred, target, inp, staged(gpu, inp)))
+        # the caller scribbles over the sky-view LUT through the pointer it kept, and tells the pipeline: the next frame
+        # recomputes it although no parameter block changed
+        alias.fill_(float("nan"))
+        sky.invalidateLUTs(gpu.abi.SZG_LUT_SKYVIEW)
+        frames.append(_frame_with(gpu, sky, deferred, target, sequence[-1], staged(gpu, sequence[-1])))
+        results[reuse] = frames
+        deferred.cleanup()
+        sky.destroy()
+    for k, (a, b) in enumerate(zip(results[False], results[True])):
+        for x, y, what in zip(a, b, ("frame", "transmittance LUT", "sky-view LUT")):
+            assert (x.view(np.uint8) == y.view(np.uint8)).all(), f"step {k}: {what} differs with LUT reuse"
+    r = results[True]
+    assert (r[0][0] == r[2][0]).all() and not (r[2][0] == r[3][0]).all()       # the sun moved: another frame
+    assert (r[4][1].view(np.uint32) == r[5][1].view(np.uint32)).all()           # camera moved: same transmittance LUT ...
+    assert not (r[4][2].view(np.uint32) == r[5][2].view(np.uint32)).all()       # ... another sky-view LUT
+    assert np.isfinite(r[7][2]).all() and (r[7][0] == r[6][0]).all()            # the scribbled LUT was recomputed
+
+
+def test_lut_reuse_skips_the_lut_passes(gpu):
+    """With reuse the second frame of an unchanged scene must not pay for the LUT passes (device time, events)."""
+    inp = util.Inputs(64, 64, elevation_degrees=35.0, spots=0)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    sky = gpu.pl.SkyViewComputePipeline.create()
+
+    def luts_ms():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        sky.recordTransmittance(None, 0, atmospheres)
+        sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    luts_ms()
+    plain = min(luts_ms() for _ in range(3))
+    sky.setLUTReuse(True)
+    first = luts_ms()
+    cached = min(luts_ms() for _ in range(3))
+    print(f"LUT passes: {plain:.3f} ms recomputed, {first:.3f} ms first frame with reuse, {cached:.3f} ms reused")
+    assert first > 0.5 * plain and cached < 0.2 * plain
+    sky.destroy()
+
+
+def test_draw_rect_offset_is_refused(gpu):
+    from syzygy_amd import SzgError
+
+    inp = util.Inputs(64, 64, spots=1)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    target = gpu.pl.SceneTexture(64, 64)
+    deferred = gpu.pl.DeferredShadingPipeline((64, 64), max_spot_lights=1, max_shadow_maps=0)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(64, 16), skyview_extent=(64, 32))
+    shifted = gpu.abi.Rect(8, 0, 32, 32)
+    with pytest.raises(SzgError, match="offset"):
+        deferred.recordDrawCommands(None, shifted, target, 1, lights, inp.spots, 0, cameras, inp.synthetic.fill)
+    with pytest.raises(SzgError, match="offset"):
+        sky.recordDrawCommands(None, target, gpu.abi.Rect(0, -4, 32, 32), deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0,
+                               cameras, 0, lights)
+    deferred.cleanup()
+    sky.destroy()
+
+
+def test_staged_buffers_survive_frames_in_flight(gpu):
+    """TStagedBuffer.recordCopyToDevice is asynchronous: three frames with three different suns are recorded back to back
+    WITHOUT a host sync in between (the copies of frame k+1 are staged while frame k's kernels have not started), each into
+    its own target; every frame - not only the last - must be its own oracle frame."""
+    W, H = 256, 144
+    lut = ((128, 32), (256, 128))
+    suns = [70.0, 20.0, 5.0]
+    inps = [util.Inputs(W, H, elevation_degrees=e, spots=3) for e in suns]
+    pl, abi = gpu.pl, gpu.abi
+    cameras = pl.TStagedBuffer(abi.CameraPacked, 1)
+    atmospheres = pl.TStagedBuffer(abi.AtmospherePacked, 1)
+    lights = pl.TStagedBuffer(abi.DirectionalLightPacked, 2)
+    targets = [pl.SceneTexture(W, H) for _ in suns]
+    deferred = pl.DeferredShadingPipeline((W, H), max_spot_lights=3, max_shadow_maps=0)
+    sky = pl.SkyViewComputePipeline.create(transmittance_extent=lut[0], skyview_extent=lut[1])
+    # a long-running kernel in front, so that every host-side staging below happens before the first copy has run
+    blocker = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    for _ in range(8):
+        blocker.mul_(1.0001)
+    for inp, target in zip(inps, targets):
+        cameras.stage([inp.cam])
+        atmospheres.stage([inp.atm])
+        lights.stage([inp.sun, inp.moon])
+        for b in (cameras, atmospheres, lights):
+            b.recordCopyToDevice()
+        deferred.recordDrawCommands(None, inp.rect, target, 1, lights, inp.spots, 0, cameras, inp.synthetic.fill)
+        sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    for inp, target, e in zip(inps, targets, suns):
+        want = render_oracle(gpu, inp, lut=lut)
+        lsb = np.abs(target.color_numpy().astype(np.int32) - want.color.astype(np.int32)).max()
+        assert lsb <= 1, (e, lsb)
+    deferred.cleanup()
+    sky.destroy()
+
+
+def test_c_abi_collectives_on_rccl_single_rank(gpu):
+    """szg_rowtile_comm (abi.h "Multi-GPU collectives") in a world of one: communicator creation, the in-place all-gather
+    of the sky-view LUT slices and the tile gather run on RCCL through the C entry points and leave the data intact."""
+    from syzygy_amd import rowtile
+
+    inp = util.Inputs(96, 64, elevation_degrees=25.0, spots=1)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    comm = rowtile.Comm(0, 1, 0)
+    assert comm.size() == 1
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(128, 32), skyview_extent=(128, 64))
+    sky.recordTransmittance(None, 0, atmospheres)
+    sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+    torch.cuda.synchronize()
+    whole = sky.download_lut(sky.skyviewLUT()).copy()
+    assert sky.lutRowSlice(0, 1) == (0, 64) and sky.lutRowSlice(3, 4) == (48, 64)
+    b, e = sky.lutRowSlice(0, 1)
+    sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, b, e)
+    comm.allgather_skyview_lut(sky).wait()
+    torch.cuda.synchronize()
+    assert (sky.download_lut(sky.skyviewLUT()).view(np.uint32) == whole.view(np.uint32)).all()
+    tile = torch.randint(-30000, 30000, (40, 96, 4), dtype=torch.int16, device="cuda")
+    gathered, work = comm.gather_tiles(tile)
+    work.wait()
+    torch.cuda.synchronize()
+    assert gathered.shape == (1, 40, 96, 4) and (gathered[0] == tile).all()
+    from syzygy_amd import SzgError
+
+    with pytest.raises(SzgError):
+        sky.lutRowSlice(0, 3)  # 64 rows do not divide over 3 ranks
+    comm.destroy()
+    sky.destroy()

@@ -1,7 +1,8 @@
 // tools/opcost.hip — VALU issue cost per opcode on gfx950, measured so that neither loop overhead nor an assumed clock can
 // pollute it (round-1's version timed 8-instruction loop bodies against an assumed 2.4 GHz):
 //   * 128 independent instructions per loop iteration in ONE asm statement (16 registers x 8; a register is reused every
-//     16 instructions, far beyond the dependent-issue latency), 512 iterations;
+//     16 instructions, far beyond the dependent-issue latency), 4096 iterations (1 - 4 ms per launch: the ramp of the
+//     dispatch is small against it);
 //   * exactly W = 1, 2, 4, 8 waves on every SIMD: one 256-thread workgroup puts one wave on each of a CU's 4 SIMDs, the
 //     dynamic LDS size admits exactly W workgroups per CU, and the grid is W x (number of CUs);
 //   * cycles from the shader clock itself: every wave brackets its loop with s_memtime (tick = shader cycle,
@@ -17,7 +18,7 @@
 #include <cstdlib>
 #include <vector>
 
-#define N_IT 512
+#define N_IT 4096
 
 #define CHECK(x)                                                                                                                  \
     do                                                                                                                            \
@@ -266,12 +267,15 @@ template <int MODE> void run(const char* name, int instructionsPerBlock = 16)
         printf(" | %dw %5.2f (wave %5.2f, %4.0f%% spread) %4.2f GHz", waves[w], perSimd, perWave, 100.0 * (mx - mn) / mx, ghz);
     }
     printf("\n");
+    fflush(stdout);
     CHECK(hipFree(d));
     CHECK(hipFree(c));
 }
 
-int main()
+int main(int argc, char** argv)
 {
+    (void)argc;
+    (void)argv;
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     g_cus = prop.multiProcessorCount;
