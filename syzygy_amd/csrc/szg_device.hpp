@@ -144,6 +144,24 @@ template <bool LEAN> SZG_DEV float sqrtPX(float x) { return LEAN ? sqrtP(x) : sq
 template <bool LEAN> SZG_DEV float safeSqrtX(float v) { return sqrtX<LEAN>(fmaxf(v, 0.0f)); }
 // exp of a value that is never NaN on a lean path (finite coefficients, radii above the lean floor)
 template <bool LEAN> SZG_DEV float expX(float x) { return LEAN ? szg_expf_notnan(x) : szg_expf(x); }
+// szg_expf (szg/fpmath.h) for x in [-86, 87], not NaN: the same reduction and polynomial, value for value. In that range the
+// clamp of the argument to [-104, 89] is the identity, q = rint(x log2 e) lies in [-125, 126] and u in (0.5, 2), so
+// u * 2^(q >> 1) and its product with 2^(q - (q >> 1)) are exact (no underflow, no overflow): (u * 2^q1) * 2^(q - q1) is
+// u * 2^q, which is what v_ldexp_f32 returns for a normal result. 9 instructions less than szg_expf_notnan.
+SZG_DEV float expInner(float x)
+{
+    float const q = __builtin_rintf(x * 1.442695040888963407359924681001892137426645954152985934135449406931f);
+    float s = __builtin_fmaf(q, -0.693145751953125f, x);
+    s = __builtin_fmaf(q, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = __builtin_fmaf(u, s, 0.00139304355252534151077271f);
+    u = __builtin_fmaf(u, s, 0.00833336077630519866943359f);
+    u = __builtin_fmaf(u, s, 0.0416664853692054748535156f);
+    u = __builtin_fmaf(u, s, 0.166666671633720397949219f);
+    u = __builtin_fmaf(u, s, 0.5f);
+    u = __builtin_fmaf(s * s, u, s) + 1.0f;
+    return __builtin_ldexpf(u, (int)q);
+}
 // (quotients of the divX sites — the two segment cosines and the smoothstep argument — are consumed sign-blind too)
 template <bool LEAN> SZG_DEV float divX(float a, float b) { return LEAN ? divR0(a, b, rcpN(b)) : a / b; }
 template <bool LEAN> SZG_DEV float divRX(float a, float b, float y) { return LEAN ? divR0(a, b, y) : a / b; }
@@ -333,6 +351,11 @@ struct Atm
     // any finite ray — the phase functions see a true cosine (phaseMie's pow(1 + g^2 - 2 g c, 1.5) is NaN for c > 1.025)
     bool sunSane;
     float extFloor2, extCeil2; // Rayleigh / Mie scattering and Rayleigh absorption carry no sign bit: partial sums are never -0
+    // Squared radius ceiling of the INNER lean march (marchLoop<true, true>): min(Ra (1 - 2^-10), Rp + 85 min(Hr, Hm)).
+    // Below it (a) every transmittance-LUT coordinate has a discriminant r^2 (mu^2 - 1) + Ra^2 >= 2^-10 Ra^2 and a distance
+    // to the shell's top >= 2^-11 Ra, far above their rounding errors, so the clamps to 0 around them never act, and (b) both
+    // densities exp(-altitude / H) have arguments in [-85, 80], where exp's result needs no two-step scaling.
+    float innerCeil2;
 };
 SZG_DEV bool plusZero3(V3 v)
 {
@@ -406,6 +429,9 @@ SZG_DEV Atm load_atm(const szg_atmosphere_packed* p)
         float const eCeil = a.atmosphereRadius + shell * 0.005f;
         a.extFloor2 = eFloor * eFloor;
         a.extCeil2 = eCeil * eCeil;
+        float const iCeil = fminf(a.atmosphereRadius * (1.0f - 0x1p-10f),
+                                  a.planetRadius + 85.0f * fminf(a.densityScaleRayleigh, a.densityScaleMie));
+        a.innerCeil2 = iCeil * iCeil;
     }
     a.rcpH = rcpN(a.lean ? a.H : 1.0f);
     a.rcpDsR = rcpN(a.lean ? a.densityScaleRayleigh : 1.0f);
@@ -421,13 +447,25 @@ struct Extinction
     V3 scatteringMie;
     V3 extinction;
 };
-template <bool LEAN = false> SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude)
+template <bool LEAN> SZG_DEV Extinction extinctionFromDensities(const Atm& a, float altitude, float densityRayleigh, float densityMie);
+template <bool LEAN = false, bool INNER = false> SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude)
 {
     // (the lean paths never see a NaN altitude: every radius along the ray is finite and above the lean floor)
+    if (LEAN && INNER)
+    {
+        // radii in [lean floor, inner ceiling]: -altitude / H in [-85, 80] for both scale heights (Atm::innerCeil2)
+        float const densityRayleigh = expInner(divR0(-altitude, a.densityScaleRayleigh, a.rcpDsR));
+        float const densityMie = expInner(divR0(-altitude, a.densityScaleMie, a.rcpDsM));
+        return extinctionFromDensities<true>(a, altitude, densityRayleigh, densityMie);
+    }
     float const densityRayleigh = expX<LEAN>(divRX<LEAN>(-altitude, a.densityScaleRayleigh, a.rcpDsR));
+    float const densityMie = expX<LEAN>(divRX<LEAN>(-altitude, a.densityScaleMie, a.rcpDsM));
+    return extinctionFromDensities<LEAN>(a, altitude, densityRayleigh, densityMie);
+}
+template <bool LEAN> SZG_DEV Extinction extinctionFromDensities(const Atm& a, float altitude, float densityRayleigh, float densityMie)
+{
     V3 const scatteringRayleigh = a.scatteringRayleigh * densityRayleigh;
     V3 const absorptionRayleigh = a.absorptionRayleigh * densityRayleigh;
-    float const densityMie = expX<LEAN>(divRX<LEAN>(-altitude, a.densityScaleMie, a.rcpDsM));
     V3 const scatteringMie = a.scatteringMie * densityMie;
     V3 const absorptionMie = a.absorptionRayleigh * densityMie;
     Extinction e;
@@ -613,9 +651,12 @@ template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const 
     p.row1 = (unsigned)(j1 * L.width);
     return p;
 }
-template <bool LEAN = false> SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, const RadiusPart& p, float mu)
+template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, const RadiusPart& p, float mu)
 {
-    float const d = fmaxf(-p.r * mu + safeSqrtX<LEAN>(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f);
+    // INNER (radius^2 <= Atm::innerCeil2, |mu| a cosine): the discriminant is >= 2^-10 Ra^2 and d >= 2^-11 Ra against
+    // rounding errors of 2^-22 relative, so max(., 0) inside safeSqrt, sqrtN's own guard and the clamp of d never act
+    float const d = (LEAN && INNER) ? (-p.r * mu + sqrtP(p.r2 * (mu * mu - 1.0f) + a.Ra2))
+                                    : fmaxf(-p.r * mu + safeSqrtX<LEAN>(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f);
     float const x_mu = divRX<LEAN>(d - p.d_min, p.denom, p.rcpDenom);
     float const s = L.u_bias + x_mu * L.u_scale;
     float const u = s * L.fwidth - 0.5f;
@@ -673,7 +714,7 @@ template <bool LEAN = false> SZG_DEV V3 sampleT_Ray(const TLut& L, const Atm& a,
 // common.glinl:114-136. The flipped branch samples with -direction, whose mu is the exact
 // negation of the unflipped one (negation commutes with every rounding), so one code path
 // with a sign select reproduces both branches.
-template <bool LEAN = false>
+template <bool LEAN = false, bool INNER = false>
 SZG_DEV V3 segmentRatio(const TLut& L, const Atm& a, const RadiusPart& pFrom, float fromDotDir, float lenFrom,
                         const RadiusPart& pTo, float toDotDir, float lenTo, float lenDir)
 {
@@ -683,8 +724,8 @@ SZG_DEV V3 segmentRatio(const TLut& L, const Atm& a, const RadiusPart& pFrom, fl
     // flip ? -mu : mu as a sign-bit XOR (one VALU op instead of a compare/select pair through VCC); for the
     // ratio, numerator and denominator are swapped by selecting the operands once rather than two quotients
     unsigned const signFlip = flip ? 0x80000000u : 0u;
-    V3 const Tf = sampleT_at<LEAN>(L, a, pFrom, xorSign(muFrom, signFlip));
-    V3 const Tt = sampleT_at<LEAN>(L, a, pTo, xorSign(muTo, signFlip));
+    V3 const Tf = sampleT_at<LEAN, INNER>(L, a, pFrom, xorSign(muFrom, signFlip));
+    V3 const Tt = sampleT_at<LEAN, INNER>(L, a, pTo, xorSign(muTo, signFlip));
     if (LEAN && L.moderate)
     {
         // both taps lie in [2^-51, 2.01]; the quotient is clamped to [0, 1] and then consumed sign-blind
@@ -745,7 +786,8 @@ struct MarchSetup
     V3 T_origin;
 };
 
-template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const MarchSetup& m)
+// INNER: every radius of the march lies below Atm::innerCeil2 (wave-uniform, decided per ray in scatteringIntegral)
+template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const MarchSetup& m)
 {
     V3 luminance = splat(0.0f);
     // `end` of step i and `begin` of step i+1 are the same expression (common.glinl:386-387),
@@ -775,7 +817,7 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         // sampleTransmittanceLUT_Sun, common.glinl:145-172
         float const sin_hz = divRX<LEAN>(a.planetRadius, s_radius, yS);
         float const cos_hz = -safeSqrtX<LEAN>(1.0f - sin_hz * sin_hz);
-        V3 const T_atm = sampleT_at<LEAN>(L, a, pStep, s_musun);
+        V3 const T_atm = sampleT_at<LEAN, INNER>(L, a, pStep, s_musun);
         float const e0 = -sin_hz * m.sin_sunRadius;
         float const e1 = sin_hz * m.sin_sunRadius;
         float const ssNum = (s_musun - cos_hz * m.cos_sunRadius) - e0, ssDen = e1 - e0;
@@ -793,14 +835,14 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
             T_sun = T_atm * angularFactor;
         }
 
-        Extinction const ex = sampleExtinction<LEAN>(a, altitude);
+        Extinction const ex = sampleExtinction<LEAN, INNER>(a, altitude);
 
         // sampleTransmittanceLUT_RayMarchStep, common.glinl:336-361
         // (t < 1e-7 -> 1, common.glinl:338-341: true for the whole wave at step 0, where the tap and the quotients are skipped)
         V3 T_begin = splat(1.0f);
         if (!waveAll(t < 0.0000001f))
         {
-            V3 const T_end = sampleT_at<LEAN>(L, a, pStep, xorSign(s_mu, m.up ? 0u : 0x80000000u));
+            V3 const T_end = sampleT_at<LEAN, INNER>(L, a, pStep, xorSign(s_mu, m.up ? 0u : 0x80000000u));
             V3 ratio;
             if (LEAN && L.moderate)
             {
@@ -830,7 +872,7 @@ template <bool LEAN> SZG_DEV V3 marchLoop(const TLut& L, const Atm& a, const Mar
         {
             segDir = normalize(segment);
         }
-        V3 const T_path = segmentRatio<LEAN>(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd,
+        V3 const T_path = segmentRatio<LEAN, INNER>(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd,
                                              sqrtPX<LEAN>(dot(segDir, segDir)));
         // 1 - T_path is 0 or a multiple of 2^-24; the extinction is in [2^-40, 2^52] when m.extLean
         V3 const oneMinusT = splat(1.0f) - T_path;
@@ -904,7 +946,13 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     // wave-uniform choice: one lane outside the domain sends its whole wave down the generic path
     if (waveAll(lean))
     {
-        return marchLoop<true>(L, a, m);
+        // the largest radius of the march is at one of its ends (|origin - t dir|^2 is convex in t); the cosines handed to
+        // the taps are quotients bounded by Cauchy-Schwarz up to rounding (|mu| <= 1 + 2^-20 is all INNER asks for)
+        if (waveAll(fmaxf(m.r2, L2) <= a.innerCeil2))
+        {
+            return marchLoop<true, true>(L, a, m);
+        }
+        return marchLoop<true, false>(L, a, m);
     }
     return marchLoop<false>(L, a, m);
 }
