@@ -663,14 +663,33 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
     float const fu = floorf(u);
     float const al = u - fu;
     float const wm1 = L.fwidth - 1.0f;
-    int const i0 = (int)__builtin_amdgcn_fmed3f(fu, 0.0f, wm1); // see radiusPart
-    int const i1 = (int)__builtin_amdgcn_fmed3f(fu + 1.0f, 0.0f, wm1);
     // only .rgb is consumed (common.glinl:111, :142): 12-byte loads keep 16 VGPRs per step out of flight
     const char* const base = reinterpret_cast<const char*>(L.texels);
-    Rgb const t00 = *reinterpret_cast<const Rgb*>(base + ((p.row0 + (unsigned)i0) << 4));
-    Rgb const t10 = *reinterpret_cast<const Rgb*>(base + ((p.row0 + (unsigned)i1) << 4));
-    Rgb const t01 = *reinterpret_cast<const Rgb*>(base + ((p.row1 + (unsigned)i0) << 4));
-    Rgb const t11 = *reinterpret_cast<const Rgb*>(base + ((p.row1 + (unsigned)i1) << 4));
+    unsigned o00, o10, o01, o11; // byte offsets of the four texels
+    if (LEAN && INNER && waveAll(fu >= 0.0f && fu <= L.fwidth - 2.0f))
+    {
+        // interior column for the whole wave (the rule; the clamps only act for rays that point into the ground, x_mu > 1, or
+        // on a rounding below 0): i0 = fu and i1 = fu + 1 are the unclamped indices and the right-hand texel of each row is
+        // the next 16 bytes: one conversion and two full-rate adds instead of two clamps, two conversions and two shifts
+        unsigned const i0 = (unsigned)(int)fu;
+        o00 = (p.row0 + i0) << 4;
+        o01 = (p.row1 + i0) << 4;
+        o10 = o00 + 16u;
+        o11 = o01 + 16u;
+    }
+    else
+    {
+        int const i0 = (int)__builtin_amdgcn_fmed3f(fu, 0.0f, wm1); // see radiusPart
+        int const i1 = (int)__builtin_amdgcn_fmed3f(fu + 1.0f, 0.0f, wm1);
+        o00 = (p.row0 + (unsigned)i0) << 4;
+        o10 = (p.row0 + (unsigned)i1) << 4;
+        o01 = (p.row1 + (unsigned)i0) << 4;
+        o11 = (p.row1 + (unsigned)i1) << 4;
+    }
+    Rgb const t00 = *reinterpret_cast<const Rgb*>(base + o00);
+    Rgb const t10 = *reinterpret_cast<const Rgb*>(base + o10);
+    Rgb const t01 = *reinterpret_cast<const Rgb*>(base + o01);
+    Rgb const t11 = *reinterpret_cast<const Rgb*>(base + o11);
     float const oma = 1.0f - al;
     float const w00 = oma * p.omb;
     float const w10 = al * p.omb;
@@ -783,6 +802,10 @@ struct MarchSetup
     float mu_sunAndStep, r_mu, two_r_mu, r2, r_musun;
     bool up;
     bool extLean; // wave-uniform: the extinction along this wave's rays is of moderate magnitude (Atm::extModerate)
+    // wave-uniform: at EVERY sample of this wave's rays the sun disc lies entirely above the local horizon, decided once per
+    // ray from bounds (scatteringIntegral); the horizon smoothstep of sampleTransmittanceLUT_Sun is then exactly 1 at every
+    // step and its operands (sin / cos of the horizon angle, the two edges) need not be formed
+    bool sunClear;
     V3 T_origin;
 };
 
@@ -815,24 +838,32 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
         float const altitude = lenBegin - a.planetRadius;
 
         // sampleTransmittanceLUT_Sun, common.glinl:145-172
-        float const sin_hz = divRX<LEAN>(a.planetRadius, s_radius, yS);
-        float const cos_hz = -safeSqrtX<LEAN>(1.0f - sin_hz * sin_hz);
         V3 const T_atm = sampleT_at<LEAN, INNER>(L, a, pStep, s_musun);
-        float const e0 = -sin_hz * m.sin_sunRadius;
-        float const e1 = sin_hz * m.sin_sunRadius;
-        float const ssNum = (s_musun - cos_hz * m.cos_sunRadius) - e0, ssDen = e1 - e0;
         V3 T_sun;
-        if (LEAN && waveAll(ssNum >= ssDen && ssDen > 0.0f))
+        if (LEAN && m.sunClear)
         {
-            // the sun disc is entirely above the sample's horizon for the whole wave: num / den >= 1 clamps to 1,
-            // smoothstep(1) = 1 * 1 * (3 - 2) = 1 and T_atm * 1 = T_atm, all exactly
+            // (the per-step test below would succeed at every step: MarchSetup::sunClear)
             T_sun = T_atm;
         }
         else
         {
-            float const ss = clampf(divX<LEAN>(ssNum, ssDen), 0.0f, 1.0f);
-            float const angularFactor = ss * ss * (3.0f - 2.0f * ss);
-            T_sun = T_atm * angularFactor;
+            float const sin_hz = divRX<LEAN>(a.planetRadius, s_radius, yS);
+            float const cos_hz = -safeSqrtX<LEAN>(1.0f - sin_hz * sin_hz);
+            float const e0 = -sin_hz * m.sin_sunRadius;
+            float const e1 = sin_hz * m.sin_sunRadius;
+            float const ssNum = (s_musun - cos_hz * m.cos_sunRadius) - e0, ssDen = e1 - e0;
+            if (LEAN && waveAll(ssNum >= ssDen && ssDen > 0.0f))
+            {
+                // the sun disc is entirely above the sample's horizon for the whole wave: num / den >= 1 clamps to 1,
+                // smoothstep(1) = 1 * 1 * (3 - 2) = 1 and T_atm * 1 = T_atm, all exactly
+                T_sun = T_atm;
+            }
+            else
+            {
+                float const ss = clampf(divX<LEAN>(ssNum, ssDen), 0.0f, 1.0f);
+                float const angularFactor = ss * ss * (3.0f - 2.0f * ss);
+                T_sun = T_atm * angularFactor;
+            }
         }
 
         Extinction const ex = sampleExtinction<LEAN, INNER>(a, altitude);
@@ -853,7 +884,8 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
             {
                 ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
             }
-            T_begin = (t < 0.0000001f) ? splat(1.0f) : ratio;
+            // (only a wave with lanes on both sides of the threshold needs the per-lane select)
+            T_begin = waveAll(!(t < 0.0000001f)) ? ratio : ((t < 0.0000001f) ? splat(1.0f) : ratio);
         }
 
         V3 const phaseTimesScattering = ex.scatteringRayleigh * m.pR + ex.scatteringMie * m.pM;
@@ -943,6 +975,17 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
                       m.sin_sunRadius >= 0x1p-30f && leanLength2(sun2) && leanLength2(direction2) && fabsf(mu) <= 2.0f &&
                       fabsf(mu_sun) <= 2.0f;
     m.extLean = waveAll(a.extModerate && rmin2 >= a.extFloor2 && fmaxf(m.r2, L2) <= a.extCeil2);
+    // sunClear. At step i the sun cosine handed to the smoothstep is s_musun = (r_musun + t * mu_sunAndStep) / s_radius with
+    // t >= 0 and mu_sunAndStep >= 0 (a safeSqrt), so its numerator is >= r_musun, and s_radius is the radius of a point of
+    // the segment: <= sqrt(max(r2, L2)) up to rounding. The test passes when s_musun >= cos_hz cos R + sin_hz sin R, and with
+    // cos_hz <= 0 <= cos R the right-hand side is at most sin_hz sin R <= (Rp / lean floor) sin R <= 1.12 sin R. Hence
+    // r_musun * 0.999 / r_max >= 1.25 sin R + 2^-10 implies ssNum >= ssDen > 0 at every step, with a margin (2^-10) a
+    // thousand times the rounding errors of the per-step expressions (which are never formed then).
+    {
+        float const rMax = sqrtf(fmaxf(m.r2, L2));
+        m.sunClear = waveAll(lean && m.cos_sunRadius >= 0.0f && m.sin_sunRadius > 0.0f && m.r_musun > 0.0f &&
+                             m.r_musun * 0.999f >= (1.25f * m.sin_sunRadius + 0x1p-10f) * rMax);
+    }
     // wave-uniform choice: one lane outside the domain sends its whole wave down the generic path
     if (waveAll(lean))
     {
