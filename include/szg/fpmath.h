@@ -36,19 +36,19 @@ SZG_FP_FN float szg_pow2i(int k) { return szg_bits_to_float((k + 127) << 23); }
 
 /* n / d for a denominator d in [1.75, 2.5] and |n| <= 0.5 (the only use: log's (m-1)/(m+1)).
  * Host: the IEEE operator. Device: the same correctly rounded quotient computed without hipcc's
- * generic denormal scaling and special-case fix-up, which cost ~47 cycles per wave64 division on
- * gfx950 against ~29 for this sequence (v_rcp_f32 seed, one Newton step, two exact fma residual
- * corrections). Operands are normal and of moderate magnitude by construction, so the result is
- * bit-identical to `/` (checked on hardware against `/` on 4.3e9 operand pairs). */
+ * generic denormal scaling and special-case fix-up (v_rcp_f32 seed, one Newton step, one exact fma
+ * residual correction). Operands are normal and of moderate magnitude by construction, so the result is
+ * bit-identical to `/` (tools/verify_div.hip, DESIGN.md "lean exact ops"). */
 SZG_FP_FN float szg_div_moderate(float n, float d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
+    /* y = RN(1 / d) (v_rcp_f32 + one Newton step: exhaustively verified, tools/verify_div.hip), q0 = RN(n y), then ONE
+     * correction with the exact residual (Markstein): the correctly rounded quotient for every operand pair of this domain
+     * (the same sequence as szg_device.hpp divR0, whose verification covers it; a zero numerator gives +0 like `/`). */
     float y = __builtin_amdgcn_rcpf(d);
     y = __builtin_fmaf(__builtin_fmaf(-d, y, 1.0f), y, y);
     float const q0 = n * y;
-    float q = __builtin_fmaf(__builtin_fmaf(-d, q0, n), y, q0);
-    q = __builtin_fmaf(__builtin_fmaf(-d, q, n), y, q);
-    return __builtin_copysignf(q, q0);
+    return __builtin_fmaf(__builtin_fmaf(-d, q0, n), y, q0);
 #else
     return n / d;
 #endif
@@ -73,8 +73,15 @@ SZG_FP_FN float szg_expf_notnan(float x)
     u = __builtin_fmaf(u, s, 0.5f);
     u = __builtin_fmaf(s * s, u, s) + 1.0f;
     int const qi = (int)q;
+#if defined(__HIP_DEVICE_COMPILE__)
+    /* The two-step scaling below in ONE instruction: the first product is exact (u in (0.5, 2), |q1| <= 76), so the value is
+     * u * 2^q rounded once - which is what v_ldexp_f32 returns, denormal, zero and infinite results included. Checked on
+     * gfx950 for every u in [0.5, 2) and every q in [-152, 130] (tools/verify_ldexp.hip, profiles/r02_verify_ldexp.txt). */
+    return __builtin_ldexpf(u, qi);
+#else
     int const q1 = qi >> 1;
     return (u * szg_pow2i(q1)) * szg_pow2i(qi - q1);
+#endif
 }
 SZG_FP_FN float szg_expf(float x)
 {
