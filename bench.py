@@ -335,6 +335,7 @@ def main():
                    "collectives": (args.backend if (world > 1 or args.force_tiled) else None),
                    "rccl_ranks": (comm.size() if comm is not None else None)},
         "pass_ms_rank0": per,
+        "source_hash": entry.source_hash("hip"),
         "roofline": roofline,
         "roofline_valu": roofline_valu,
         "roofline_frame": {"algorithmic_bytes": frame_bytes, "device_ms": frame_s * 1e3,

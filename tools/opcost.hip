@@ -42,7 +42,7 @@
 enum Mode
 {
     FMA, MUL, ADD, MUL64, MOV, PKFMA, PKMUL, RCP, RSQ, SQRT, EXP, LOG, FLOOR, FRACT, CVT_I, CVT_F, MAX, MIN, MED3, MINI, ADDU,
-    BFI, XOR, LSHL, MULLO, ADDLSHL, DIVFIXUP, DIVSCALE, DIVFMAS, CMP, CMPX_PAIR, CNDMASK, CMP_CND, READLANE, SNOP, LDEXP, FREXP,
+    BFI, XOR, LSHL, MULLO, ADDLSHL, DIVFIXUP, DIVSCALE, DIVFMAS, CMP, CNDMASK, FMAC, SUB, CND_SGPR, MAX3, CMP_CND, READLANE, SNOP, LDEXP, FREXP,
     ANDOR, MAD_U24, DPP_ROW, FMA_DEP, NMODES
 };
 
@@ -75,6 +75,10 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, unsigne
     if (u == 0)                                                                                                                   \
     asm volatile(L128(INS) : R16_OUT : "v"(a), "v"(b) : "vcc")
 #define F_FMA(R) "v_fma_f32 " R ", " R ", %16, %17\n"
+#define F_FMAC(R) "v_fmac_f32 " R ", %16, %17\n"
+#define F_SUB(R) "v_sub_f32 " R ", " R ", %16\n"
+#define F_MAX3(R) "v_max3_f32 " R ", " R ", %16, %17\n"
+#define F_CND_SGPR(R) "v_cndmask_b32_e64 " R ", " R ", %16, %18\n"
 #define F_MUL(R) "v_mul_f32 " R ", " R ", %16\n"
 #define F_ADD(R) "v_add_f32 " R ", " R ", %16\n"
 #define F_MUL64(R) "v_mul_f32_e64 " R ", " R ", %16\n"
@@ -111,6 +115,14 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, unsigne
 #define F_MAD24(R) "v_mad_u32_u24 " R ", " R ", %16, %17\n"
 #define F_DPP(R) "v_add_f32_dpp " R ", " R ", %16 row_shr:1 row_mask:0xf bank_mask:0xf\n"
             if (MODE == FMA) A1(F_FMA);
+            if (MODE == FMAC) A1(F_FMAC);
+            if (MODE == SUB) A1(F_SUB);
+            if (MODE == MAX3) A1(F_MAX3);
+            if (MODE == CND_SGPR)
+            {
+                if (u == 0)
+                    asm volatile(L128(F_CND_SGPR) : R16_OUT : "v"(a), "v"(b), "s"(0x5555555555555555ull));
+            }
             if (MODE == MUL) A1(F_MUL);
             if (MODE == ADD) A1(F_ADD);
             if (MODE == MUL64) A1(F_MUL64);
@@ -176,21 +188,6 @@ template <int MODE> __global__ __launch_bounds__(256) void k(float* out, unsigne
                              : "=&s"(s0), "=&s"(s1), "=&s"(s2), "=&s"(s3)
                              : "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7]));
                 sacc += s0 ^ s1 ^ s2 ^ s3;
-            }
-            if (MODE == CMPX_PAIR)
-            {
-                // what a divergent `if` costs around its body: save exec, v_cmpx, restore (s_and_saveexec form)
-                asm volatile("v_cmp_lt_f32 vcc, %0, %16\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %1, %1, %16\n s_or_b64 exec, exec, s[20:21]\n"
-                             "v_cmp_lt_f32 vcc, %2, %16\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %3, %3, %16\n s_or_b64 exec, exec, s[20:21]\n"
-                             "v_cmp_lt_f32 vcc, %4, %16\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %5, %5, %16\n s_or_b64 exec, exec, s[20:21]\n"
-                             "v_cmp_lt_f32 vcc, %6, %16\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %7, %7, %16\n s_or_b64 exec, exec, s[20:21]\n"
-                             "v_cmp_lt_f32 vcc, %8, %16\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %9, %9, %16\n s_or_b64 exec, exec, s[20:21]\n"
-                             "v_cmp_lt_f32 vcc, %10, %16\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %11, %11, %16\n s_or_b64 exec, exec, s[20:21]\n"
-                             "v_cmp_lt_f32 vcc, %12, %16\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %13, %13, %16\n s_or_b64 exec, exec, s[20:21]\n"
-                             "v_cmp_lt_f32 vcc, %14, %16\n s_and_saveexec_b64 s[20:21], vcc\n v_add_f32 %15, %15, %16\n s_or_b64 exec, exec, s[20:21]\n"
-                             : R16_OUT
-                             : "v"(1.0e30f), "v"(b)
-                             : "vcc", "s20", "s21");
             }
             if (MODE == FMA_DEP)
             {
@@ -261,10 +258,13 @@ template <int MODE> void run(const char* name, int instructionsPerBlock = 16)
             mn = v < mn ? (double)v : mn;
         }
         double instr = (double)N_IT * 8 * instructionsPerBlock;
-        double perWave = sum / h.size() / instr;          // cycles per instruction seen by one wave
-        double perSimd = perWave / waves[w];              // the SIMD's issue cost: W waves share it
-        double ghz = (mx / 1e9) / (ms * 1e-3);            // slowest wave spans (almost) the whole launch
-        printf(" | %dw %5.2f (wave %5.2f, %4.0f%% spread) %4.2f GHz", waves[w], perSimd, perWave, 100.0 * (mx - mn) / mx, ghz);
+        // The SIMD issues the W waves' instructions within the span of its slowest wave (waves of one launch start together;
+        // the arbiter may favour the oldest, so single waves finish early): cost per instruction = slowest wave / (W x count).
+        // The mean over the waves is printed beside it; equal figures mean the waves shared the SIMD evenly.
+        double perSimd = mx / instr / waves[w];
+        double meanWave = sum / h.size() / instr;
+        double ghz = (mx / 1e9) / (ms * 1e-3);
+        printf(" | %dw %5.2f (mean wave %5.2f) %4.2f GHz", waves[w], perSimd, meanWave, ghz);
     }
     printf("\n");
     fflush(stdout);
@@ -279,10 +279,10 @@ int main(int argc, char** argv)
     hipDeviceProp_t prop;
     CHECK(hipGetDeviceProperties(&prop, 0));
     g_cus = prop.multiProcessorCount;
-    printf("# %s, %d CUs; SIMD-cycles per wave64 instruction from s_memtime (shader clock), W waves per SIMD; per-wave cost; spread of\n"
-           "# the per-wave cycle counts; effective clock = slowest wave's cycles / launch wall time\n",
+    printf("# %s, %d CUs. Per opcode, for W = 1, 2, 4, 8 waves per SIMD: SIMD-cycles per wave64 instruction = slowest wave's s_memtime\n"
+           "# span / (W x instructions); (mean cycles per instruction seen by one wave); effective clock = that span / launch wall time.\n",
            prop.gcnArchName, g_cus);
-    run<FMA>("v_fma_f32"); run<MUL>("v_mul_f32"); run<ADD>("v_add_f32"); run<MUL64>("v_mul_f32_e64"); run<MOV>("v_mov_b32");
+    run<FMA>("v_fma_f32"); run<FMAC>("v_fmac_f32 (VOP2)"); run<MUL>("v_mul_f32"); run<SUB>("v_sub_f32"); run<ADD>("v_add_f32"); run<MUL64>("v_mul_f32_e64"); run<MOV>("v_mov_b32");
     run<PKFMA>("v_pk_fma_f32"); run<PKMUL>("v_pk_mul_f32");
     run<RCP>("v_rcp_f32"); run<RSQ>("v_rsq_f32"); run<SQRT>("v_sqrt_f32"); run<EXP>("v_exp_f32"); run<LOG>("v_log_f32");
     run<FLOOR>("v_floor_f32"); run<FRACT>("v_fract_f32"); run<CVT_I>("v_cvt_i32_f32"); run<CVT_F>("v_cvt_f32_i32");
@@ -291,8 +291,8 @@ int main(int argc, char** argv)
     run<ADDU>("v_add_u32"); run<XOR>("v_xor_b32"); run<LSHL>("v_lshlrev_b32"); run<BFI>("v_bfi_b32"); run<ANDOR>("v_and_or_b32");
     run<MULLO>("v_mul_lo_u32"); run<MAD_U24>("v_mad_u32_u24"); run<ADDLSHL>("v_add_lshl_u32");
     run<DIVSCALE>("v_div_scale_f32"); run<DIVFMAS>("v_div_fmas_f32"); run<DIVFIXUP>("v_div_fixup_f32");
-    run<CMP>("v_cmp_lt_f32 -> vcc"); run<CNDMASK>("v_cndmask_b32 (vcc)"); run<CMP_CND>("cmp + cndmask pair", 32);
-    run<CMPX_PAIR>("cmp+saveexec+add+or", 32); run<DPP_ROW>("v_add_f32 dpp row_shr"); run<READLANE>("v_readlane_b32");
+    run<CMP>("v_cmp_lt_f32 -> vcc"); run<CNDMASK>("v_cndmask_b32 (vcc)"); run<CND_SGPR>("v_cndmask_b32 (sgpr mask)"); run<MAX3>("v_max3_f32"); run<CMP_CND>("cmp + cndmask pair", 32);
+    run<DPP_ROW>("v_add_f32 dpp row_shr"); run<READLANE>("v_readlane_b32");
     run<SNOP>("s_nop 0"); run<FMA_DEP>("v_fma_f32 dependent");
     return 0;
 }
