@@ -308,13 +308,12 @@ SZG_DEV bool leanNumerator(float a) { return a == 0.0f || fabsf(a) >= 0x1p-60f; 
 SZG_DEV float sqrtU(bool lean, float x) { return lean ? sqrtN(x) : sqrtf(x); }
 
 // One light's term of the sum (lights.comp:141-161), exact.
-SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool positionModerate, V3 viewDirection, bool cullable)
+// `clip`: shadowMatrix * vec4(position, 1), rows x, y, w summed left to right (projectRows below: the cone test and the
+// exact evaluation share one evaluation of the three rows; R[k] * 1.0f of the shader's product is R[k] itself)
+SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool positionModerate, V3 viewDirection, bool cullable, V3 clip)
 {
     const float* R = L.shadowRows;
-    // shadowMatrix * vec4(position, 1), rows summed left to right
-    float const cx = R[0] * m.position.x + R[1] * m.position.y + R[2] * m.position.z + R[3] * 1.0f;
-    float const cy = R[4] * m.position.x + R[5] * m.position.y + R[6] * m.position.z + R[7] * 1.0f;
-    float const cw = R[12] * m.position.x + R[13] * m.position.y + R[14] * m.position.z + R[15] * 1.0f;
+    float const cx = clip.x, cy = clip.y, cw = clip.z;
     bool const isSpot = L.isSpot != 0u;
     V3 const lightDir = mk3(L.dir[0], L.dir[1], L.dir[2]);
     V3 const toLight = mk3(L.position[0], L.position[1], L.position[2]) - m.position;
@@ -380,9 +379,14 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     // computeLightContribution, lights.comp:93-108 (brdfMix of szg_device.hpp with the half vector shared above)
     float const hinv = lean ? divN(1.0f, sqrtN(hd)) : 1.0f / sqrtf(hd);
     V3 const h = hs * hinv;
-    float const microfacet = szg_powf(clampf(dot(h, m.normal), 0.0f, 1.0f), m.specularPower);
+    // both pow() without their special-case selects when no lane of the wave has a zero / denormal / non-finite base or a
+    // zero exponent (szg_device.hpp powLean: the same values)
+    float const baseSpecular = clampf(dot(h, m.normal), 0.0f, 1.0f);
+    float const baseFresnel = 1.0f - clampf(dot(h, lightDir), 0.0f, 1.0f);
+    bool const powsLean = waveAll(powLeanOK(baseSpecular, m.specularPower) && powLeanOK(baseFresnel, 5.0f));
+    float const microfacet = powsLean ? powLean(baseSpecular, m.specularPower) : szg_powf(baseSpecular, m.specularPower);
     V3 const specular = splat(m.normalization * microfacet);
-    float const p = szg_powf(1.0f - clampf(dot(h, lightDir), 0.0f, 1.0f), 5.0f);
+    float const p = powsLean ? powLean(baseFresnel, 5.0f) : szg_powf(baseFresnel, 5.0f);
     V3 const fresnel = m.reflectance + (splat(1.0f) - m.reflectance) * p;
     V3 const brdf = mix(m.diffuse, specular, fresnel);
     // lights.comp:106-107
@@ -408,11 +412,17 @@ SZG_DEV LightCull loadCull(const LightRec* __restrict__ L)
     c.isSpot = L->isSpot;
     return c;
 }
-SZG_DEV bool surelyOutsideCone(const LightCull& c, V3 p)
+// rows x, y and w of shadowMatrix * vec4(p, 1), each summed left to right as the shader does
+SZG_DEV V3 projectRows(const LightCull& c, V3 p)
 {
     float const cx = c.rx[0] * p.x + c.rx[1] * p.y + c.rx[2] * p.z + c.rx[3];
     float const cy = c.ry[0] * p.x + c.ry[1] * p.y + c.ry[2] * p.z + c.ry[3];
     float const cw = c.rw[0] * p.x + c.rw[1] * p.y + c.rw[2] * p.z + c.rw[3];
+    return V3{cx, cy, cw};
+}
+SZG_DEV bool surelyOutsideCone(V3 clip)
+{
+    float const cx = clip.x, cy = clip.y, cw = clip.z;
     float const acw = fabsf(cw);
     float const ax = fabsf(cx - 0.5f * cw);
     float const ay = fabsf(cy - 0.5f * cw);
@@ -466,11 +476,12 @@ __global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug
             const LightRec* __restrict__ L = lights + i;
             LightCull const cur = loadCull(L); // (prefetching light i+1's rows here measured 20 % slower)
             bool const cullable = waveFinite && L->pad[0] != 0u;
-            if (cur.isSpot != 0u && cullable && surelyOutsideCone(cur, m.position))
+            V3 const clip = projectRows(cur, m.position);
+            if (cur.isSpot != 0u && cullable && surelyOutsideCone(clip))
             {
                 continue;
             }
-            sum = sum + lightContribution(*L, m, positionModerate, viewDirection, cullable);
+            sum = sum + lightContribution(*L, m, positionModerate, viewDirection, cullable, clip);
         }
     }
     row_ptr<uint2>(color, y)[x] = pack_unorm16x4(sum.x, sum.y, sum.z, 1.0f);

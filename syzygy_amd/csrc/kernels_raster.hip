@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64) void k_raster_setup(const RasterDraw* __restric
                 // edge functions are rounding noise (a camera a million units away) or the triangle projects to a line (a
                 // zero column in the projection): regions the oracle, which tests every pixel, shades too.
                 float fx0 = 0.0f, fx1 = (float)W, fy0 = 0.0f, fy1 = (float)H;
+                bool boxed = false; // the box below is the bounding box of T' (not the viewport fallback)
                 if (allFront)
                 {
                     float pushed[3];
@@ -249,6 +250,7 @@ __global__ __launch_bounds__(64) void k_raster_setup(const RasterDraw* __restric
                     }
                     if (defined)
                     {
+                        boxed = true;
                         fx0 = fmaxf(fminf(fminf(x[0], x[1]), x[2]) - 1.0f, 0.0f);
                         fx1 = fminf(fmaxf(fmaxf(x[0], x[1]), x[2]) + 1.0f, (float)W);
                         fy0 = fmaxf(fminf(fminf(y[0], y[1]), y[2]) - 1.0f, 0.0f);
@@ -259,7 +261,17 @@ __global__ __launch_bounds__(64) void k_raster_setup(const RasterDraw* __restric
                 minY = (int)fy0;
                 maxX = min((int)fx1, (int)W - 1);
                 maxY = min((int)fy1, (int)H - 1);
-                if (!(fx0 <= fx1) || !(fy0 <= fy1)) // NaN-safe: keep the viewport
+                if (boxed && (fx0 > fx1 || fy0 > fy1))
+                {
+                    // the bounding box of T' is finite (its corners are numbers: `defined`) and misses the viewport: a
+                    // primitive wholly off-screen that the per-plane rejection did not catch. No pixel can pass the
+                    // edge tests, so it is culled like an invalid one instead of being handed to every pixel patch.
+                    minX = 65535;
+                    maxX = 0;
+                    minY = 65535;
+                    maxY = 0;
+                }
+                else if (!(fx0 <= fx1) || !(fy0 <= fy1)) // NaN-safe: keep the viewport
                 {
                     minX = 0;
                     minY = 0;

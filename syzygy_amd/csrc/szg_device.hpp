@@ -177,6 +177,33 @@ SZG_DEV float divN0(float a, float b) { return divR0(a, b, rcpN(b)); }
 // ballots from an int predicate, ~15 instructions per use)
 SZG_DEV bool waveAll(bool c) { return __builtin_amdgcn_ballot_w64(!c) == 0ull; }
 
+// szg_powf(x, y) (szg/fpmath.h: exp(y * log x) with GLSL's special cases) for a base that is a positive NORMAL number
+// (2^-126 <= x < inf) and an exponent that is a finite number other than 0 - the same operations value for value, without
+// the selects that cannot fire there: log's denormal pre-scaling (x >= 2^-126) and its x == inf / x == 0 / x < 0 / NaN
+// cases, exp's NaN pass-through (the argument y * log x is a finite product), pow's x == 0 and y == 0 cases. The clamp of
+// exp's argument stays: x^160 underflows for most bases.
+SZG_DEV float powLean(float x, float y)
+{
+    int const bits = szg_float_to_bits(x * 1.3333333333333333333333333333333333333f);
+    int const e = ((bits >> 23) & 0xFF) - 127;
+    float const m = szg_bits_to_float(szg_float_to_bits(x) - (e << 23));
+    float const t = szg_div_moderate(m - 1.0f, m + 1.0f);
+    float const t2 = t * t;
+    float p = 0.2392828464508056640625f;
+    p = __builtin_fmaf(p, t2, 0.28518211841583251953125f);
+    p = __builtin_fmaf(p, t2, 0.400005877017974853515625f);
+    p = __builtin_fmaf(p, t2, 0.666666686534881591796875f);
+    p = __builtin_fmaf(p, t2, 2.0f);
+    float const fe = (float)e;
+    float const lg = __builtin_fmaf(t, p, 0.693147180559945286226764f * fe);
+    return szg_expf_notnan(y * lg);
+}
+// wave-uniform precondition of powLean
+SZG_DEV bool powLeanOK(float x, float y)
+{
+    return x >= 1.17549435e-38f && x <= 0x1p127f && fabsf(y) >= 0x1p-100f && fabsf(y) <= 0x1p20f;
+}
+
 // column-major 4x4 times (x, y, z, w), rows summed left to right
 struct M4
 {
