@@ -153,7 +153,27 @@ def main():
         gathered = [torch.empty((nranks, stride_rows, W, 4), dtype=torch.int16, device=dev) for _ in range(2)]
         composed = torch.empty((H, W, 4), dtype=torch.int16, device=dev)
 
-    comm = rowtile.Comm(rank, world, local_rank) if ((world > 1 or args.force_tiled) and args.backend == "nccl") else None
+    # Data plane of the row-tiled frame: the C-ABI's RCCL collectives. Should the communicator not come up on some rank
+    # (all ranks agree through the control group), torch.distributed's own RCCL backend takes over: same collectives.
+    comm, torch_group, collective_api = None, None, None
+    if (world > 1 or args.force_tiled) and args.backend == "nccl":
+        ok = 1
+        try:
+            comm = rowtile.Comm(rank, world, local_rank)
+            collective_api = "szg_rowtile_comm (C-ABI, RCCL)"
+        except Exception as e:
+            log(f"rank {rank}: szg_rowtile_comm failed ({e}); falling back to torch.distributed's RCCL backend")
+            ok = 0
+        agreed = torch.tensor([ok], dtype=torch.int32)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) == 0:
+            if comm is not None:
+                comm.destroy()
+                comm = None
+            torch_group = dist.new_group(backend="nccl")
+            collective_api = "torch.distributed (RCCL)"
+    elif world > 1 or args.force_tiled:
+        collective_api = "torch.distributed (gloo, host-staged rehearsal)"
     sky_lut = sky.skyviewLUT_tensor() if (tiled and comm is None) else None
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(args.steps)]
     spot_arg = spots if SPOTS else None
@@ -192,7 +212,7 @@ def main():
             if comm is not None:
                 lut_work = comm.allgather_skyview_lut(sky)
             else:
-                lut_work = rowtile.allgather_lut(sky_lut, rank, nranks, async_op=True, force=True)
+                lut_work = rowtile.allgather_lut(sky_lut, rank, nranks, group=torch_group, async_op=True, force=True)
                 sky.invalidateLUTs(abi.SZG_LUT_SKYVIEW)  # texels written through the aliased tensor
             if e:
                 e[1].record()
@@ -225,7 +245,7 @@ def main():
                 buf, work = comm.gather_tiles(tgt.color, gathered=gathered[k % 2] if rank == 0 else None, dst=0)
             else:
                 buf, work = rowtile.gather_tiles(tgt.color, rank, nranks, gathered=gathered[k % 2] if rank == 0 else None,
-                                                 async_op=True)
+                                                 group=torch_group, async_op=True)
             pending.append((buf, work))
         if e:
             e[5].record()
@@ -333,7 +353,7 @@ def main():
                    "sun_elevation_deg": args.elevation, "row_tile_block_rows": BLOCK_ROWS if tiled else None,
                    "parallelism": (f"rowtile{nranks}+gather" if tiled else ("single" if world == 1 else f"replicas{world}")),
                    "collectives": (args.backend if (world > 1 or args.force_tiled) else None),
-                   "rccl_ranks": (comm.size() if comm is not None else None)},
+                   "collective_api": collective_api, "rccl_ranks": (comm.size() if comm is not None else None)},
         "pass_ms_rank0": per,
         "source_hash": entry.source_hash("hip"),
         "roofline": roofline,

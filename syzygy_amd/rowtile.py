@@ -73,12 +73,20 @@ class Comm:
     def __init__(self, rank, nranks, device_index=0, bootstrap_group=None):
         self.rank, self.nranks = int(rank), int(nranks)
         blob = C.create_string_buffer(abi.SZG_ROWTILE_COMM_ID_BYTES)
+        failure = None
         if self.rank == 0:
-            check(lib().szg_rowtile_comm_unique_id(blob))
+            try:
+                check(lib().szg_rowtile_comm_unique_id(blob))
+            except Exception as e:  # RCCL missing: tell the other ranks instead of leaving them in the broadcast
+                failure = e
         if self.nranks > 1:
-            box = [bytes(blob.raw)]
+            box = [b"" if failure is not None else bytes(blob.raw)]
             dist.broadcast_object_list(box, src=0, group=bootstrap_group)
+            if len(box[0]) != abi.SZG_ROWTILE_COMM_ID_BYTES:
+                raise RuntimeError(f"rank 0 could not create the communicator id: {failure}")
             blob = C.create_string_buffer(box[0], abi.SZG_ROWTILE_COMM_ID_BYTES)
+        elif failure is not None:
+            raise failure
         handle = C.c_void_p()
         check(lib().szg_rowtile_comm_create(C.byref(handle), self.rank, self.nranks, blob, int(device_index)))
         self._h = handle
