@@ -103,6 +103,38 @@ def test_null_arguments_are_rejected():
     assert b"szg_record_oetf" in lib().szg_last_error()
 
 
+def test_round2_entry_points_reject_bad_arguments_without_a_device():
+    """The multi-GPU collectives, LUT reuse and row-slice entry points: NULL / inconsistent arguments are refused before
+    anything touches a device (and before RCCL is loaded)."""
+    L = lib()
+    assert L.szg_rowtile_comm_unique_id(None) == -1
+    handle = C.c_void_p()
+    blob = C.create_string_buffer(abi.SZG_ROWTILE_COMM_ID_BYTES)
+    assert L.szg_rowtile_comm_create(None, 0, 1, blob, 0) == -1
+    assert L.szg_rowtile_comm_create(C.byref(handle), 2, 2, blob, 0) == -1 and not handle.value  # rank outside [0, nranks)
+    assert L.szg_rowtile_comm_create(C.byref(handle), 0, 1, None, 0) == -1
+    assert L.szg_rowtile_gather(None, None, None, 0, None, 0) == -1
+    assert L.szg_rowtile_allgather(None, None, None, 0) == -1
+    assert L.szg_rowtile_comm_rank(None) == -1 and L.szg_rowtile_comm_size(None) == -1
+    L.szg_rowtile_comm_destroy(None)
+    assert L.szg_skyview_set_lut_reuse(None, 1) == -1
+    assert L.szg_skyview_invalidate_luts(None, abi.SZG_LUT_SKYVIEW) == -1
+    b, e = C.c_uint32(), C.c_uint32()
+    assert L.szg_skyview_lut_row_slice(None, 0, 1, C.byref(b), C.byref(e)) == -1
+    assert L.szg_skyview_allgather_lut_rows(None, None, None) == -1
+
+
+def test_communicator_needs_a_device():
+    torch = pytest.importorskip("torch")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    handle = C.c_void_p()
+    blob = C.create_string_buffer(abi.SZG_ROWTILE_COMM_ID_BYTES)
+    # no GPU here: either RCCL cannot be loaded or there is no HIP device; never a communicator, never a CPU stand-in
+    status = lib().szg_rowtile_comm_create(C.byref(handle), 0, 1, blob, 0)
+    assert status == -2 and not handle.value
+
+
 def test_host_raster_helpers_need_no_device():
     """szg_transform_matrix / szg_tick_mesh_instance / szg_calculate_shadow_bounds are CPU-only (include/szg/host.h)."""
     m = abi.Mat4()

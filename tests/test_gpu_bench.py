@@ -51,6 +51,19 @@ def test_bench_under_an_external_launcher_and_forced_tiling_on_rccl():
     assert one["image_checksum"] == two["image_checksum"]
 
 
+def test_bench_roofline_names_the_dominant_kernel_of_each_workload():
+    """`roofline` describes the longest pass of the run it belongs to, and takes `traffic` only from the committed counter
+    profile of the same workload and kernel (profiles/r02_pmc_<workload>.json)."""
+    c5 = _run([sys.executable, "bench.py", "--workload", "c5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert c5["roofline"]["kernel"] == "k_lights" and c5["roofline"]["avg_launch_ms"] == pytest.approx(c5["pass_ms_rank0"]["lights"])
+    assert c5["roofline"]["algorithmic_bytes_per_launch"] == 56 * 3840 * 2160
+    assert c5["roofline"]["traffic"] is not None and c5["roofline"]["traffic_source"].endswith("r02_pmc_c5.json")
+    c3 = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert c3["roofline"]["kernel"] == "k_composite" and c3["roofline_valu"]["kernel"] == "k_composite"
+    assert 0.5 < c3["roofline_valu"]["frac_of_issue_ceiling_at_2.4GHz"] < 1.0
+    assert len(c3["source_hash"]) == 16
+
+
 def test_example_frame_loop_runs():
     """examples/frame_loop.py: scene tick -> shadow bounds -> baked atmosphere -> mesh raster -> lights -> atmosphere ->
     OETF for a few animated frames; the image must be finite, opaque and not black."""
