@@ -105,6 +105,14 @@ def test_random_sweep_tools_find_nothing(tool, first, last, extra=()):
     assert "mismatching seeds: 0" in r.stdout, r.stdout[-2000:]
 
 
+def test_random_sweep_of_lut_reuse():
+    """tools/random_sweep_lut_reuse.py: a long-lived pipeline with LUT reuse on a random walk of parameter changes, repeats,
+    scribbled texels and invalidations; after every frame its LUTs equal a fresh pipeline's."""
+    r = subprocess.run([sys.executable, "tools/random_sweep_lut_reuse.py", "0", "40"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "done, mismatching seeds: 0" in r.stdout, r.stdout[-2000:]
+
+
 def test_random_sweep_with_degenerate_lut_extents():
     """LUTs of 2 ... 7 texels a side: their marches produce NaN texels in perfectly sane atmospheres, which only the sky-view
     LUT's status word (not any inference from the parameters) can tell the composite (seeds 1721, 1884 mismatched before it)."""

@@ -1064,12 +1064,14 @@ def test_c5_full_size_frame_chain(gpu):
 # ---------------------------------------------------------------------------
 # round 2: LUT reuse, explicit invalidation, draw-rect offsets, staging ring, C-ABI collectives
 # ---------------------------------------------------------------------------
-def _frame_with(gpu, sky, deferred, target, inp, staged_buffers):
+def _frame_with(gpu, sky, deferred, target, inp, staged_buffers, lut_images):
+    """One frame; returns (colour, transmittance LUT, sky-view LUT). `lut_images` were fetched once up front: every accessor
+    call tells the pipeline that the caller may write the texels, which forces a recompute and would hide what reuse does."""
     cameras, atmospheres, lights = staged_buffers
     deferred.recordDrawCommands(None, inp.rect, target, 1, lights, inp.spots if inp.spot_count else None, 0, cameras, inp.synthetic.fill)
     sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
     torch.cuda.synchronize()
-    return target.color_numpy().copy(), sky.download_lut(sky.transmittanceLUT()).copy(), sky.download_lut(sky.skyviewLUT()).copy()
+    return target.color_numpy().copy(), sky.download_lut(lut_images[0]).copy(), sky.download_lut(lut_images[1]).copy()
 
 
 def test_lut_reuse_gives_identical_frames_and_tracks_every_input(gpu):
@@ -1091,17 +1093,18 @@ def test_lut_reuse_gives_identical_frames_and_tracks_every_input(gpu):
     for reuse in (False, True):
         sky = gpu.pl.SkyViewComputePipeline.create(**lut)
         alias = sky.skyviewLUT_tensor()  # a pointer the caller keeps for later
+        lut_images = (sky.transmittanceLUT(), sky.skyviewLUT())
         sky.setLUTReuse(reuse)
         deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=2, max_shadow_maps=0)
         target = gpu.pl.SceneTexture(W, H)
         frames = []
         for inp in sequence:
-            frames.append(_frame_with(gpu, sky, deferred, target, inp, staged(gpu, inp)))
+            frames.append(_frame_with(gpu, sky, deferred, target, inp, staged(gpu, inp), lut_images))
         # the caller scribbles over the sky-view LUT through the pointer it kept, and tells the pipeline: the next frame
         # recomputes it although no parameter block changed
         alias.fill_(float("nan"))
         sky.invalidateLUTs(gpu.abi.SZG_LUT_SKYVIEW)
-        frames.append(_frame_with(gpu, sky, deferred, target, sequence[-1], staged(gpu, sequence[-1])))
+        frames.append(_frame_with(gpu, sky, deferred, target, sequence[-1], staged(gpu, sequence[-1]), lut_images))
         results[reuse] = frames
         deferred.cleanup()
         sky.destroy()
