@@ -366,12 +366,12 @@ def main():
         # N = 1 of the default run is the 4K workload the metric is quoted on; the strong-scaling base of THIS workload
         # (same 8K frame on one GPU, untiled) is a committed measurement, repeated here so that the speed-up can be read
         # off the line without mixing workloads.
-        ref = os.path.join(ROOT, "profiles", "r01_j_bench_c4_1gpu.json")
+        ref = os.path.join(ROOT, "profiles", "r02_bench_c4.json")
         if os.path.exists(ref):
             try:
                 r1 = json.load(open(ref))
                 out["strong_scaling_reference"] = {"workload": name, "n_gpus": 1, "value": r1["value"], "ms_per_step": r1["ms_per_step"],
-                                                   "image_checksum": r1.get("image_checksum"), "source": "profiles/r01_j_bench_c4_1gpu.json",
+                                                   "image_checksum": r1.get("image_checksum"), "source": "profiles/r02_bench_c4.json",
                                                    "speedup_vs_reference": value / r1["value"]}
             except Exception:
                 pass

@@ -1228,3 +1228,45 @@ def test_c_abi_collectives_on_rccl_single_rank(gpu):
         sky.lutRowSlice(0, 3)  # 64 rows do not divide over 3 ranks
     comm.destroy()
     sky.destroy()
+
+
+def test_texels_written_through_a_kept_pointer_are_rescanned_after_invalidate(gpu):
+    """ADVICE (round 1): the pipeline keeps a status word per LUT (sky-view: "every texel finite") that lets the composite
+    leave samples of non-metal pixels unevaluated. A caller that writes texels through a pointer it kept must say so
+    (szg_skyview_invalidate_luts); the next composite then re-scans the texels, and a NaN LUT poisons exactly the pixels it
+    poisons in the oracle - 0 * NaN in the reflection term of every geometry pixel included."""
+    W, H = 96, 64
+    inp = util.Inputs(W, H, elevation_degrees=30.0, spots=2)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    lut = ((128, 32), (128, 64))
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=lut[0], skyview_extent=lut[1])
+    alias = sky.skyviewLUT_tensor()  # kept
+    im_t = sky.transmittanceLUT()
+    target = gpu.pl.SceneTexture(W, H, debug=True)
+    deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=2, max_shadow_maps=0)
+    deferred.recordDrawCommands(None, inp.rect, target, 1, lights, inp.spots, 0, cameras, inp.synthetic.fill)
+    prior = target.color.clone()
+    sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    clean = target.debug.cpu().numpy().copy()
+    assert np.isfinite(clean).all()
+    tlut = sky.download_lut(im_t).copy()
+    # scribble: half of the LUT becomes NaN, behind the pipeline's back; then the notice, then a composite ALONE
+    alias[: lut[1][1] // 2].fill_(float("nan"))
+    torch.cuda.synchronize()
+    slut = alias.cpu().numpy().copy()
+    sky.invalidateLUTs(gpu.abi.SZG_LUT_SKYVIEW)
+    target.color.copy_(prior)
+    sky.recordComposite(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    got = target.debug.cpu().numpy()
+    frame = gpu.ob.HostFrame(W, H)
+    gpu.ob.gbuffer_fill(frame, inp.rect, None, inp.cam, inp.synthetic.fill, threads=8)
+    gpu.ob.lights(frame, inp.rect, None, None, inp.cam, inp.dirs, 2, 1, inp.spots, 2, threads=8)
+    gpu.ob.composite(frame, inp.rect, None, None, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=8)
+    assert (np.isnan(got) == np.isnan(frame.debug)).all(), "NaN pattern differs from the oracle's"
+    assert np.isnan(got).any() and not np.isnan(got).all()
+    ok = ~np.isnan(got)
+    assert (got[ok].view(np.uint32) == frame.debug[ok].view(np.uint32)).all()
+    deferred.cleanup()
+    sky.destroy()
