@@ -379,9 +379,10 @@ struct Atm
     bool sunSane;
     float extFloor2, extCeil2; // Rayleigh / Mie scattering and Rayleigh absorption carry no sign bit: partial sums are never -0
     // Squared radius ceiling of the INNER lean march (marchLoop<true, true>): min(Ra (1 - 2^-10), Rp + 85 min(Hr, Hm)).
-    // Below it (a) every transmittance-LUT coordinate has a discriminant r^2 (mu^2 - 1) + Ra^2 >= 2^-10 Ra^2 and a distance
-    // to the shell's top >= 2^-11 Ra, far above their rounding errors, so the clamps to 0 around them never act, and (b) both
-    // densities exp(-altitude / H) have arguments in [-85, 80], where exp's result needs no two-step scaling.
+    // Below it (a) every transmittance-LUT coordinate has a discriminant r^2 (mu^2 - 1) + Ra^2 >= 2^-10 Ra^2, far above its
+    // rounding error, so the clamp to 0 under its square root never acts (the clamp of the distance itself stays: NaN cosines
+    // of zero-length segments rely on it), and (b) both densities exp(-altitude / H) have arguments in [-85, 80], where the
+    // clamp of exp's argument is the identity.
     float innerCeil2;
 };
 SZG_DEV bool plusZero3(V3 v)
@@ -680,9 +681,12 @@ template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const 
 }
 template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLut& L, const Atm& a, const RadiusPart& p, float mu)
 {
-    // INNER (radius^2 <= Atm::innerCeil2, |mu| a cosine): the discriminant is >= 2^-10 Ra^2 and d >= 2^-11 Ra against
-    // rounding errors of 2^-22 relative, so max(., 0) inside safeSqrt, sqrtN's own guard and the clamp of d never act
-    float const d = (LEAN && INNER) ? (-p.r * mu + sqrtP(p.r2 * (mu * mu - 1.0f) + a.Ra2))
+    // INNER (radius^2 <= Atm::innerCeil2): for a mu that is a number the discriminant is >= 2^-10 Ra^2 against rounding
+    // errors of 2^-22 relative, so max(., 0) inside safeSqrt and sqrtN's own guard never act. The clamp of d STAYS: mu is NaN
+    // where a march segment has length 0 (geometry nearer than 32 ulps of the planet radius, ~15 m: normalize(0) = NaN,
+    // common.glinl:114-136), and max(NaN, 0) = 0 is what the reference then samples with (found by the 6 000-seed sweep of
+    // round 2: a version without this clamp let the NaN through to the texel weights in 8 of 6 000 random frames).
+    float const d = (LEAN && INNER) ? fmaxf(-p.r * mu + sqrtP(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f)
                                     : fmaxf(-p.r * mu + safeSqrtX<LEAN>(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f);
     float const x_mu = divRX<LEAN>(d - p.d_min, p.denom, p.rcpDenom);
     float const s = L.u_bias + x_mu * L.u_scale;

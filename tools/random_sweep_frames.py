@@ -66,5 +66,10 @@ for seed in range(int(sys.argv[1]), int(sys.argv[2])):
     if not same:
         bad+=1; ne=(got.view(np.uint32)!=fr.debug.view(np.uint32))&~(np.isnan(got)&np.isnan(fr.debug))
         print('seed',seed,'MISMATCH',ne.sum(),'of',ne.size,'W,H',W,H,'luts',tl,sl,'spots',nsp,'tile',(nranks,block,rank),'maps',list(maps),'skip',skip,'nan gpu/oracle',np.isnan(got).sum(),np.isnan(fr.debug).sum(),flush=True)
+        if __import__('os').environ.get('SZG_SWEEP_VERBOSE'):
+            gl=sky.download_lut(sky.skyviewLUT()); print('  sky-view LUT texels differing:',int((gl.view(np.uint32)!=slut.view(np.uint32)).sum()),'transmittance:',int((sky.download_lut(sky.transmittanceLUT()).view(np.uint32)!=tlut.view(np.uint32)).sum()))
+            ys,xs=np.nonzero(ne.any(axis=-1))
+            for y,x in list(zip(ys,xs))[:8]:
+                print('  px',int(x),int(y),'depth',float(fr.depth[y,x]),'metal',float(fr.orm[y,x,2]),'gpu',got[y,x,:3],'oracle',fr.debug[y,x,:3],'pos',fr.position[y,x,:3])
     deferred.cleanup(); sky.destroy()
 print('done, mismatching seeds:',bad)
