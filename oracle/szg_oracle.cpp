@@ -16,8 +16,26 @@
 // — i.e. "parity unpinned by reference tests"; see DESIGN.md.
 //
 // Numerics: every GLSL operation is evaluated in fp32 in the order written in
-// the shader; compile with -O2 -ffp-contract=off (no FMA contraction, no
-// fast-math). The implementation-defined GLSL built-ins (exp, pow, sin, cos,
+// the shader; compile with -O2 -ffp-contract=off (the COMPILER contracts
+// nothing, no fast-math).
+// CONTRACTION RULE (round 2). The reference's shaders carry no `precise`
+// qualifier and its committed SPIR-V not one NoContraction decoration
+// (tests/test_spv_layout.py), so a Vulkan implementation may evaluate a * b + c
+// with one rounding, and dot(), matrix * vector and mix() are single SPIR-V
+// instructions (OpDot, OpMatrixTimesVector, FMix) whose inner arithmetic is the
+// implementation's; texture filtering is fixed function altogether. This
+// restatement, like every shader compiler for real hardware, therefore uses
+// fused multiply-adds - explicitly (fmaf), at exactly these places, keeping the
+// shader's order of additions, and the HIP kernels do the same at the same places:
+//   dot(a, b)            = fma(az, bz, fma(ay, by, ax * bx))
+//   (M * v).row          = fma(m3, vw, fma(m2, vz, fma(m1, vy, m0 * vx)))
+//   mix(a, b, w)         = fma(b, w, a * (1 - w))
+//   bilinear fetch       = fma(w11, t11, fma(w01, t01, fma(w10, t10, w00 * t00))), texel coordinate fma(s, W, -0.5)
+//   LUT coordinate maps  = fma(x, 1 - 1/N, 0.5/N);  d = max(fma(-r, mu, sqrt(fma(r*r, fma(mu, mu, -1), Ra^2))), 0)
+//   march geometry       = origin - t * dir as fma(-t, dir, origin);  fma(2 r mu, t, t*t) + r*r;  fma(t, mu_step, r * mu_sun)
+//   march accumulation   = fma(sM, pM, sR * pR);  luminance = fma(p * s * i, t, luminance)
+// Everything else is one rounding per written operation.
+// The implementation-defined GLSL built-ins (exp, pow, sin, cos,
 // asin, acos) are the pinned fp32 algorithms of include/szg/fpmath.h, or libm
 // with -DSZG_ORACLE_LIBM (see below); sqrt and / are IEEE correctly rounded. Sampler semantics are SURVEY
 // Appendix A: fp32 bilinear with clamp-to-edge, nearest clamp-to-edge, nearest
@@ -81,7 +99,7 @@ struct vec4
 inline vec2 operator+(vec2 a, vec2 b) { return {a.x + b.x, a.y + b.y}; }
 inline vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
 inline vec2 operator*(vec2 a, float s) { return {a.x * s, a.y * s}; }
-inline float dot(vec2 a, vec2 b) { return a.x * b.x + a.y * b.y; }
+inline float dot(vec2 a, vec2 b) { return fmaf(a.y, b.y, a.x * b.x); } // OpDot: contraction rule, file header
 
 inline vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -103,7 +121,7 @@ inline vec3& operator*=(vec3& a, vec3 b)
     return a;
 }
 
-inline float dot(vec3 a, vec3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+inline float dot(vec3 a, vec3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); } // OpDot
 inline float length(vec3 a) { return sqrtf(dot(a, a)); }
 inline float length(vec2 a) { return sqrtf(dot(a, a)); }
 inline float distance(vec3 a, vec3 b) { return length(a - b); }
@@ -117,9 +135,13 @@ inline vec3 clamp(vec3 v, float lo, float hi) { return {clampf(v.x, lo, hi), cla
 // mix(a, b, w) = a*(1-w) + b*w
 inline vec3 mix(vec3 a, vec3 b, vec3 w)
 {
-    return {a.x * (1.0f - w.x) + b.x * w.x, a.y * (1.0f - w.y) + b.y * w.y, a.z * (1.0f - w.z) + b.z * w.z};
+    return {fmaf(b.x, w.x, a.x * (1.0f - w.x)), fmaf(b.y, w.y, a.y * (1.0f - w.y)), fmaf(b.z, w.z, a.z * (1.0f - w.z))};
 }
 inline vec3 mix(vec3 a, vec3 b, float w) { return mix(a, b, vec3(w)); }
+// contracted forms of  a * s + c,  a * b + c  and  c - t * d  (one rounding per component)
+inline vec3 fma3(vec3 a, float s, vec3 c) { return {fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)}; }
+inline vec3 fma3(vec3 a, vec3 b, vec3 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)}; }
+inline vec3 fnma(float t, vec3 d, vec3 c) { return {fmaf(-t, d.x, c.x), fmaf(-t, d.y, c.y), fmaf(-t, d.z, c.z)}; }
 inline float smoothstep(float e0, float e1, float x)
 {
     float const t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
@@ -142,10 +164,10 @@ inline mat4 load(const szg_mat4& s)
 inline vec4 operator*(const mat4& a, vec4 v)
 {
     vec4 r;
-    r.x = a.m[0] * v.x + a.m[4] * v.y + a.m[8] * v.z + a.m[12] * v.w;
-    r.y = a.m[1] * v.x + a.m[5] * v.y + a.m[9] * v.z + a.m[13] * v.w;
-    r.z = a.m[2] * v.x + a.m[6] * v.y + a.m[10] * v.z + a.m[14] * v.w;
-    r.w = a.m[3] * v.x + a.m[7] * v.y + a.m[11] * v.z + a.m[15] * v.w;
+    r.x = fmaf(a.m[12], v.w, fmaf(a.m[8], v.z, fmaf(a.m[4], v.y, a.m[0] * v.x)));
+    r.y = fmaf(a.m[13], v.w, fmaf(a.m[9], v.z, fmaf(a.m[5], v.y, a.m[1] * v.x)));
+    r.z = fmaf(a.m[14], v.w, fmaf(a.m[10], v.z, fmaf(a.m[6], v.y, a.m[2] * v.x)));
+    r.w = fmaf(a.m[15], v.w, fmaf(a.m[11], v.z, fmaf(a.m[7], v.y, a.m[3] * v.x)));
     return r;
 }
 // mat4 * mat4: column j of the result = a * (column j of b)
@@ -308,8 +330,8 @@ inline float sample_depth_border(const Image& im, vec2 uv)
 // texture() LINEAR / CLAMP_TO_EDGE, no mips, fp32 weights (skyview.cpp:199-207, :339-346)
 inline vec3 sample_linear_rgb(const Image& im, vec2 st)
 {
-    float const u = st.x * (float)im.width - 0.5f;
-    float const v = st.y * (float)im.height - 0.5f;
+    float const u = fmaf(st.x, (float)im.width, -0.5f);
+    float const v = fmaf(st.y, (float)im.height, -0.5f);
     float const fu = floorf(u);
     float const fv = floorf(v);
     float const a = u - fu;
@@ -330,9 +352,9 @@ inline vec3 sample_linear_rgb(const Image& im, vec2 st)
     float const w01 = (1.0f - a) * b;
     float const w11 = a * b;
     vec3 r;
-    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
-    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
-    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    r.x = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
+    r.y = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
+    r.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -393,7 +415,7 @@ inline float safeSqrt(float value) { return sqrtf(fmaxf(value, 0.0f)); }
 // common.glinl:29-32
 inline float textureCoordFromUnitRange(float value, int dimension)
 {
-    return 0.5f / (float)dimension + value * (1.0f - 1.0f / (float)dimension);
+    return fmaf(value, 1.0f - 1.0f / (float)dimension, 0.5f / (float)dimension);
 }
 // common.glinl:33-36
 inline float unitRangeFromTextureCoord(float texCoord, int dimension)
@@ -408,7 +430,7 @@ vec2 transmittanceLUT_RMu_to_UV(const Atmosphere& atmosphere, const Transmittanc
     float const planetRadiusMmSquared = atmosphere.planetRadiusMm * atmosphere.planetRadiusMm;
     float const H = safeSqrt(atmospherRadiusMmSquared - planetRadiusMmSquared);
     float const rho = safeSqrt(radius * radius - planetRadiusMmSquared);
-    float const d = fmaxf(-radius * mu + safeSqrt(radius * radius * (mu * mu - 1.0f) + atmospherRadiusMmSquared), 0.0f);
+    float const d = fmaxf(fmaf(-radius, mu, safeSqrt(fmaf(radius * radius, fmaf(mu, mu, -1.0f), atmospherRadiusMmSquared))), 0.0f);
     float const d_min = atmosphere.atmosphereRadiusMm - radius;
     float const d_max = rho + H;
     float const x_mu = (d - d_min) / (d_max - d_min);
@@ -611,9 +633,9 @@ RaymarchStep stepRadiusMu(RaymarchStep start, float stepDistance)
         safeSqrt(start.mu_sun * start.mu - safeSqrt((1.0f - start.mu_sun * start.mu_sun) * (1.0f - start.mu * start.mu)));
     RaymarchStep result;
     result.radius =
-        safeSqrt(stepDistance * stepDistance + 2.0f * start.radius * start.mu * stepDistance + start.radius * start.radius);
+        safeSqrt(fmaf(2.0f * start.radius * start.mu, stepDistance, stepDistance * stepDistance) + start.radius * start.radius);
     result.mu = (start.radius * start.mu + stepDistance) / result.radius;
-    result.mu_sun = (start.radius * start.mu_sun + stepDistance * mu_sunAndStepDirection) / result.radius;
+    result.mu_sun = fmaf(stepDistance, mu_sunAndStepDirection, start.radius * start.mu_sun) / result.radius;
     return result;
 }
 
@@ -656,8 +678,8 @@ vec3 computeLuminanceScatteringIntegral(const Atmosphere& atmosphere, const Tran
     for (uint32_t i = 0; i < SKY_VIEW_LUT_SAMPLE_COUNT; i++)
     {
         float const t = (float)i * dSampleDistance;
-        vec3 const begin = origin - ((float)i * dSampleDistance) * scatteringDir;
-        vec3 const end = origin - ((float)(i + 1) * dSampleDistance) * scatteringDir;
+        vec3 const begin = fnma(((float)i * dSampleDistance), scatteringDir, origin);
+        vec3 const end = fnma(((float)(i + 1) * dSampleDistance), scatteringDir, origin);
 
         RaymarchStep const sampleStep = stepRadiusMu(originStep, t);
         float const altitude = length(begin) - atmosphere.planetRadiusMm;
@@ -667,14 +689,14 @@ vec3 computeLuminanceScatteringIntegral(const Atmosphere& atmosphere, const Tran
 
         vec3 const transmittanceToBegin = sampleTransmittanceLUT_RayMarchStep(atmosphere, transmittanceLUT, originStep, t);
         float const incidentCosine = dot(atmosphere.incidentDirectionSun, scatteringDir);
-        vec3 const phaseTimesScattering = extinctionSample.scatteringRayleigh * phaseRayleigh(incidentCosine) +
-                                          extinctionSample.scatteringMie * phaseMie(incidentCosine, 0.8f);
+        vec3 const phaseTimesScattering = fma3(extinctionSample.scatteringMie, phaseMie(incidentCosine, 0.8f),
+                                               extinctionSample.scatteringRayleigh * phaseRayleigh(incidentCosine));
         vec3 const shadowing = transmittanceToSun;
 
         vec3 const transmittanceAlongPath = sampleTransmittanceLUT_Segment(transmittanceLUT, atmosphere, begin, end);
         vec3 const scatteringIlluminanceIntegral = (vec3(1.0f) - transmittanceAlongPath) / extinctionSample.extinction;
 
-        luminance += phaseTimesScattering * shadowing * scatteringIlluminanceIntegral * transmittanceToBegin;
+        luminance = fma3(phaseTimesScattering * shadowing * scatteringIlluminanceIntegral, transmittanceToBegin, luminance);
     }
     return luminance;
 }

@@ -44,8 +44,14 @@ SZG_DEV V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
 SZG_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
 SZG_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 SZG_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
-SZG_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-SZG_DEV float dot(V2 a, V2 b) { return a.x * b.x + a.y * b.y; }
+// Contraction rule (oracle/szg_oracle.cpp header): dot, matrix * vector, mix, bilinear fetches, the LUT coordinate maps and
+// the march's geometry / accumulation use fused multiply-adds, explicitly and at the same places as the oracle; the
+// compiler itself contracts nothing (-ffp-contract=off).
+SZG_DEV float dot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
+SZG_DEV float dot(V2 a, V2 b) { return __builtin_fmaf(a.y, b.y, a.x * b.x); }
+SZG_DEV V3 fma3(V3 a, float s, V3 c) { return V3{__builtin_fmaf(a.x, s, c.x), __builtin_fmaf(a.y, s, c.y), __builtin_fmaf(a.z, s, c.z)}; }
+SZG_DEV V3 fma3(V3 a, V3 b, V3 c) { return V3{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z)}; }
+SZG_DEV V3 fnma(float t, V3 d, V3 c) { return V3{__builtin_fmaf(-t, d.x, c.x), __builtin_fmaf(-t, d.y, c.y), __builtin_fmaf(-t, d.z, c.z)}; }
 SZG_DEV float length(V3 a) { return sqrtf(dot(a, a)); }
 SZG_DEV V3 normalize(V3 v)
 {
@@ -61,7 +67,8 @@ SZG_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), h
 SZG_DEV V3 clamp01(V3 v) { return V3{clampf(v.x, 0.0f, 1.0f), clampf(v.y, 0.0f, 1.0f), clampf(v.z, 0.0f, 1.0f)}; }
 SZG_DEV V3 mix(V3 a, V3 b, V3 w)
 {
-    return V3{a.x * (1.0f - w.x) + b.x * w.x, a.y * (1.0f - w.y) + b.y * w.y, a.z * (1.0f - w.z) + b.z * w.z};
+    return V3{__builtin_fmaf(b.x, w.x, a.x * (1.0f - w.x)), __builtin_fmaf(b.y, w.y, a.y * (1.0f - w.y)),
+              __builtin_fmaf(b.z, w.z, a.z * (1.0f - w.z))};
 }
 SZG_DEV float smoothstep(float e0, float e1, float x)
 {
@@ -212,10 +219,10 @@ struct M4
 SZG_DEV V4 mul(const M4& a, float x, float y, float z, float w)
 {
     V4 r;
-    r.x = a.m[0] * x + a.m[4] * y + a.m[8] * z + a.m[12] * w;
-    r.y = a.m[1] * x + a.m[5] * y + a.m[9] * z + a.m[13] * w;
-    r.z = a.m[2] * x + a.m[6] * y + a.m[10] * z + a.m[14] * w;
-    r.w = a.m[3] * x + a.m[7] * y + a.m[11] * z + a.m[15] * w;
+    r.x = __builtin_fmaf(a.m[12], w, __builtin_fmaf(a.m[8], z, __builtin_fmaf(a.m[4], y, a.m[0] * x)));
+    r.y = __builtin_fmaf(a.m[13], w, __builtin_fmaf(a.m[9], z, __builtin_fmaf(a.m[5], y, a.m[1] * x)));
+    r.z = __builtin_fmaf(a.m[14], w, __builtin_fmaf(a.m[10], z, __builtin_fmaf(a.m[6], y, a.m[2] * x)));
+    r.w = __builtin_fmaf(a.m[15], w, __builtin_fmaf(a.m[11], z, __builtin_fmaf(a.m[7], y, a.m[3] * x)));
     return r;
 }
 SZG_DEV M4 mul(const M4& a, const M4& b)
@@ -608,8 +615,8 @@ SZG_DEV TLut make_tlut(const float4* texels, int w, int h)
 
 SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float fW, float fH, float s, float t)
 {
-    float const u = s * fW - 0.5f;
-    float const v = t * fH - 0.5f;
+    float const u = __builtin_fmaf(s, fW, -0.5f);
+    float const v = __builtin_fmaf(t, fH, -0.5f);
     float const fu = floorf(u);
     float const fv = floorf(v);
     float const a = u - fu;
@@ -629,9 +636,9 @@ SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float f
     float const w01 = (1.0f - a) * b;
     float const w11 = a * b;
     V3 r;
-    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
-    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
-    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    r.x = __builtin_fmaf(w11, t11.x, __builtin_fmaf(w01, t01.x, __builtin_fmaf(w10, t10.x, w00 * t00.x)));
+    r.y = __builtin_fmaf(w11, t11.y, __builtin_fmaf(w01, t01.y, __builtin_fmaf(w10, t10.y, w00 * t00.y)));
+    r.z = __builtin_fmaf(w11, t11.z, __builtin_fmaf(w01, t01.z, __builtin_fmaf(w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -663,8 +670,8 @@ template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const 
     p.denom = d_max - p.d_min;
     p.rcpDenom = LEAN ? rcpN(p.denom) : 0.0f;
     float const x_radius = divRX<LEAN>(rho, a.H, a.rcpH);
-    float const t = L.v_bias + x_radius * L.v_scale;
-    float const v = t * L.fheight - 0.5f;
+    float const t = __builtin_fmaf(x_radius, L.v_scale, L.v_bias);
+    float const v = __builtin_fmaf(t, L.fheight, -0.5f);
     float const fv = floorf(v);
     p.b = v - fv;
     p.omb = 1.0f - p.b;
@@ -686,11 +693,11 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
     // where a march segment has length 0 (geometry nearer than 32 ulps of the planet radius, ~15 m: normalize(0) = NaN,
     // common.glinl:114-136), and max(NaN, 0) = 0 is what the reference then samples with (found by the 6 000-seed sweep of
     // round 2: a version without this clamp let the NaN through to the texel weights in 8 of 6 000 random frames).
-    float const d = (LEAN && INNER) ? fmaxf(-p.r * mu + sqrtP(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f)
-                                    : fmaxf(-p.r * mu + safeSqrtX<LEAN>(p.r2 * (mu * mu - 1.0f) + a.Ra2), 0.0f);
+    float const disc = __builtin_fmaf(p.r2, __builtin_fmaf(mu, mu, -1.0f), a.Ra2);
+    float const d = fmaxf(__builtin_fmaf(-p.r, mu, (LEAN && INNER) ? sqrtP(disc) : safeSqrtX<LEAN>(disc)), 0.0f);
     float const x_mu = divRX<LEAN>(d - p.d_min, p.denom, p.rcpDenom);
-    float const s = L.u_bias + x_mu * L.u_scale;
-    float const u = s * L.fwidth - 0.5f;
+    float const s = __builtin_fmaf(x_mu, L.u_scale, L.u_bias);
+    float const u = __builtin_fmaf(s, L.fwidth, -0.5f);
     float const fu = floorf(u);
     float const al = u - fu;
     float const wm1 = L.fwidth - 1.0f;
@@ -727,9 +734,9 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
     float const w01 = oma * p.b;
     float const w11 = al * p.b;
     V3 r;
-    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
-    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
-    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    r.x = __builtin_fmaf(w11, t11.x, __builtin_fmaf(w01, t01.x, __builtin_fmaf(w10, t10.x, w00 * t00.x)));
+    r.y = __builtin_fmaf(w11, t11.y, __builtin_fmaf(w01, t01.y, __builtin_fmaf(w10, t10.y, w00 * t00.y)));
+    r.z = __builtin_fmaf(w11, t11.z, __builtin_fmaf(w01, t01.z, __builtin_fmaf(w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -846,7 +853,7 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
     V3 luminance = splat(0.0f);
     // `end` of step i and `begin` of step i+1 are the same expression (common.glinl:386-387),
     // so its length and radius part are carried from one iteration to the next.
-    V3 begin = m.origin - (0.0f * m.dS) * m.scatteringDir;
+    V3 begin = fnma(0.0f * m.dS, m.scatteringDir, m.origin);
     float lenBegin = sqrtPX<LEAN>(dot(begin, begin));
     RadiusPart pBegin = radiusPart<LEAN>(L, a, lenBegin);
 #pragma unroll 1
@@ -854,16 +861,17 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
     {
         float const fi = (float)i;
         float const t = fi * m.dS;
-        V3 const end = m.origin - ((float)(i + 1u) * m.dS) * m.scatteringDir;
+        V3 const end = fnma((float)(i + 1u) * m.dS, m.scatteringDir, m.origin);
         float const lenEnd = sqrtPX<LEAN>(dot(end, end));
         RadiusPart const pEnd = radiusPart<LEAN>(L, a, lenEnd);
 
         // stepRadiusMu(originStep, t), common.glinl:329-331
         // (on a lean path this is a squared radius above the lean floor: neither the clamp to 0 nor sqrtN's guard is needed)
-        float const s_radius = LEAN ? sqrtP(t * t + m.two_r_mu * t + m.r2) : safeSqrt(t * t + m.two_r_mu * t + m.r2);
+        float const s_q = __builtin_fmaf(m.two_r_mu, t, t * t) + m.r2;
+        float const s_radius = LEAN ? sqrtP(s_q) : safeSqrt(s_q);
         float const yS = LEAN ? rcpN(s_radius) : 0.0f;
         float const s_mu = divRX<LEAN>(m.r_mu + t, s_radius, yS);
-        float const s_musun = divRX<LEAN>(m.r_musun + t * m.mu_sunAndStep, s_radius, yS);
+        float const s_musun = divRX<LEAN>(__builtin_fmaf(t, m.mu_sunAndStep, m.r_musun), s_radius, yS);
         RadiusPart const pStep = radiusPart<LEAN>(L, a, s_radius);
 
         float const altitude = lenBegin - a.planetRadius;
@@ -919,7 +927,7 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
             T_begin = waveAll(!(t < 0.0000001f)) ? ratio : ((t < 0.0000001f) ? splat(1.0f) : ratio);
         }
 
-        V3 const phaseTimesScattering = ex.scatteringRayleigh * m.pR + ex.scatteringMie * m.pM;
+        V3 const phaseTimesScattering = fma3(ex.scatteringMie, m.pM, ex.scatteringRayleigh * m.pR);
 
         // sampleTransmittanceLUT_Segment(begin, end), common.glinl:114-136. The segment can be arbitrarily short
         // (geometry close to the camera: end - begin may even be 0 and its normal NaN), so normalize() keeps the
@@ -942,7 +950,7 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
         V3 const integral = (LEAN && m.extLean) ? V3{divN0(oneMinusT.x, ex.extinction.x), divN0(oneMinusT.y, ex.extinction.y),
                                                      divN0(oneMinusT.z, ex.extinction.z)}
                                                 : oneMinusT / ex.extinction;
-        luminance = luminance + phaseTimesScattering * T_sun * integral * T_begin;
+        luminance = fma3(phaseTimesScattering * T_sun * integral, T_begin, luminance);
 
         begin = end;
         lenBegin = lenEnd;
@@ -997,7 +1005,7 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     // leanRay: every radius met along the path stays >= 0.9 Rp and of moderate magnitude, the path length is
     // moderate, and the smoothstep span 2 * sin_hz * sin(sunRadius) is a normal number. The closest approach of
     // the segment [0, L] to the planet centre is at t* = -r*mu when that lies inside the segment.
-    float const L2 = sampleDistance * sampleDistance + m.two_r_mu * sampleDistance + m.r2;
+    float const L2 = __builtin_fmaf(m.two_r_mu, sampleDistance, sampleDistance * sampleDistance) + m.r2; // stepRadiusMu's form
     float const tStar = -m.r_mu;
     float const rmin2 = (tStar > 0.0f && tStar < sampleDistance) ? m.r2 * (1.0f - mu * mu) : fminf(m.r2, L2);
     // ... and the two cosines are cosines: a sun (or view) vector of length 0 or inf makes mu_sun (mu) infinite or NaN, and

@@ -34,7 +34,26 @@ def reflect():
     if not os.path.exists(TOOL) or not all(os.path.exists(p) for p in paths):
         return None
     out = subprocess.run([TOOL] + paths, check=True, capture_output=True, text=True).stdout
-    return json.loads(out)
+    data = json.loads(out)
+    # What the reflection library does not report: whether the shaders forbid fused multiply-adds anywhere. Counted from the
+    # SPIR-V words themselves (SPIR-V 1.x: OpDecorate = 71, OpMemberDecorate = 72, Decoration NoContraction = 42).
+    import struct
+
+    for path in paths:
+        blob = open(path, "rb").read()
+        words = struct.unpack("<%dI" % (len(blob) // 4), blob)
+        assert words[0] == 0x07230203
+        i, counts = 5, {"no_contraction": 0, "OpFMul": 0, "OpFAdd": 0, "OpFSub": 0, "OpDot": 0, "OpMatrixTimesVector": 0}
+        while i < len(words):
+            op, n = words[i] & 0xFFFF, words[i] >> 16
+            if (op == 71 and words[i + 2] == 42) or (op == 72 and words[i + 3] == 42):
+                counts["no_contraction"] += 1
+            for name, code in (("OpFMul", 133), ("OpFAdd", 129), ("OpFSub", 131), ("OpDot", 148), ("OpMatrixTimesVector", 145)):
+                if op == code:
+                    counts[name] += 1
+            i += n
+        data[os.path.basename(path)]["arithmetic"] = counts
+    return data
 
 
 if __name__ == "__main__":

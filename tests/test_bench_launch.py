@@ -21,4 +21,6 @@ def test_gpus_n_without_a_launcher_starts_its_own_ranks():
     assert r.returncode != 0
     assert r.stdout.strip() == ""  # no line is better than a wrong line
     assert "self-launch:" in r.stderr and "--nproc-per-node=2" in r.stderr
-    assert r.stderr.count("bench.py needs a GPU") >= 2  # both ranks started and reached the device check
+    # the ranks started and reached the device check (the launcher tears the second one down as soon as the first fails,
+    # so one message is all that is guaranteed)
+    assert r.stderr.count("bench.py needs a GPU") >= 1

@@ -176,6 +176,18 @@ def test_workgroup_formats_and_bindings(golden):
     assert binding("oetf_srgb.comp.spv", "image")["descriptor_type"] == STORAGE_IMAGE
 
 
+def test_the_reference_shaders_permit_contraction(golden):
+    """The contraction rule of oracle/szg_oracle.cpp (dot, matrix * vector, mix, a * b + c evaluated with fused multiply-adds)
+    rests on this: not one NoContraction decoration in the committed SPIR-V of the path (and no `precise` in the GLSL), while
+    the shaders are full of OpFMul / OpFAdd pairs, OpDot and OpMatrixTimesVector whose evaluation Vulkan leaves to the
+    implementation."""
+    for name in ("transmittance_LUT.comp.spv", "skyview_LUT.comp.spv", "camera.comp.spv", "lights.comp.spv", "offscreen.vert.spv"):
+        counts = golden[name]["arithmetic"]
+        assert counts["no_contraction"] == 0, name
+    assert golden["camera.comp.spv"]["arithmetic"]["OpFMul"] > 50 and golden["camera.comp.spv"]["arithmetic"]["OpDot"] > 5
+    assert golden["lights.comp.spv"]["arithmetic"]["OpMatrixTimesVector"] >= 1
+
+
 def test_raster_push_constants_name_the_buffers_raster_h_takes(golden):
     """offscreen.vert / depthpass.vert read vertices, model matrices (64 B stride) and cameras / light matrices through
     buffer references: the arrays szg_mesh_instanced and the shadow pass take (include/szg/raster.h)."""
