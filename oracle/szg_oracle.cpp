@@ -170,6 +170,19 @@ inline vec4 operator*(const mat4& a, vec4 v)
     r.w = fmaf(a.m[15], v.w, fmaf(a.m[11], v.z, fmaf(a.m[7], v.y, a.m[3] * v.x)));
     return r;
 }
+// glm's mat4 * mat4 as HOST code evaluates it: one rounding per operation (for matrices the reference computes on the CPU)
+inline mat4 mul_glm(const mat4& a, const mat4& b)
+{
+    mat4 r;
+    for (int j = 0; j < 4; j++)
+    {
+        for (int i = 0; i < 4; i++)
+        {
+            r.m[j * 4 + i] = a.m[i] * b.m[j * 4 + 0] + a.m[4 + i] * b.m[j * 4 + 1] + a.m[8 + i] * b.m[j * 4 + 2] + a.m[12 + i] * b.m[j * 4 + 3];
+        }
+    }
+    return r;
+}
 // mat4 * mat4: column j of the result = a * (column j of b)
 inline mat4 operator*(const mat4& a, const mat4& b)
 {
@@ -1654,7 +1667,7 @@ static mat4 inverse4(const mat4& m)
 void oracle_shadow_map(const szg_mat4* projection, const szg_mat4* view, uint32_t dim, const szg_fill_scene* geometry, float* out,
                        int threads)
 {
-    mat4 const pv = load(*projection) * load(*view);
+    mat4 const pv = mul_glm(load(*projection), load(*view)); // host-side in the reference (shadowpass.cpp:188-248): glm, no fma
     mat4 const inv = inverse4(pv);
     parallel_rows(dim, threads, [&](uint32_t r0, uint32_t r1) {
         for (uint32_t y = r0; y < r1; y++)

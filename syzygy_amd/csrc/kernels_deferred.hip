@@ -538,8 +538,9 @@ __global__ void k_shadow_prep(const szg_directional_light_packed* __restrict__ d
     if (i < dirCount + spotCount && owned[i].map != nullptr)
     {
         // light.projection * light.view (shadowpass.cpp:207-215)
-        pv = (i < dirCount) ? mul(load_m4(dirs[i].projection), load_m4(dirs[i].view))
-                            : mul(load_m4(spots[i - dirCount].projection), load_m4(spots[i - dirCount].view));
+        // (a host-side product in the reference: glm semantics, not the shaders' contraction rule)
+        pv = (i < dirCount) ? mulGlm(load_m4(dirs[i].projection), load_m4(dirs[i].view))
+                            : mulGlm(load_m4(spots[i - dirCount].projection), load_m4(spots[i - dirCount].view));
         g.map = const_cast<float*>(owned[i].map);
         g.dim = owned[i].width;
         g.pitchFloats = owned[i].pitchFloats;

@@ -239,6 +239,23 @@ SZG_DEV M4 mul(const M4& a, const M4& b)
     }
     return r;
 }
+// glm's mat4 * mat4 as the reference's HOST code evaluates it (one rounding per operation, columns combined left to right:
+// host_scene.cpp szg_mat4_mul): for matrices the reference computes on the CPU and hands to a shader - the per-light
+// projView of the shadow passes (shadowpass.cpp:188-248) - as opposed to products written in a shader (mul above).
+SZG_DEV M4 mulGlm(const M4& a, const M4& b)
+{
+    M4 r;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+            r.m[j * 4 + i] = a.m[i] * b.m[j * 4 + 0] + a.m[4 + i] * b.m[j * 4 + 1] + a.m[8 + i] * b.m[j * 4 + 2] + a.m[12 + i] * b.m[j * 4 + 3];
+        }
+    }
+    return r;
+}
 // glm::inverse(mat4) (cofactor expansion, glm/detail/func_matrix.inl), same operation order as host_scene.cpp
 SZG_DEV M4 inverse4(const M4& m)
 {
