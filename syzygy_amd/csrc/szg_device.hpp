@@ -499,8 +499,9 @@ struct Extinction
     V3 scatteringMie;
     V3 extinction;
 };
-template <bool LEAN> SZG_DEV Extinction extinctionFromDensities(const Atm& a, float altitude, float densityRayleigh, float densityMie);
-template <bool LEAN = false, bool INNER = false> SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude)
+template <bool LEAN>
+SZG_DEV Extinction extinctionFromDensities(const Atm& a, float altitude, float densityRayleigh, float densityMie, bool belowOzone);
+template <bool LEAN = false, bool INNER = false> SZG_DEV Extinction sampleExtinction(const Atm& a, float altitude, bool belowOzone = false)
 {
     // (the lean paths never see a NaN altitude: every radius along the ray is finite and above the lean floor)
     if (LEAN && INNER)
@@ -508,13 +509,16 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV Extinction sampleExtinc
         // radii in [lean floor, inner ceiling]: -altitude / H in [-85, 80] for both scale heights (Atm::innerCeil2)
         float const densityRayleigh = expInner(divR0(-altitude, a.densityScaleRayleigh, a.rcpDsR));
         float const densityMie = expInner(divR0(-altitude, a.densityScaleMie, a.rcpDsM));
-        return extinctionFromDensities<true>(a, altitude, densityRayleigh, densityMie);
+        return extinctionFromDensities<true>(a, altitude, densityRayleigh, densityMie, belowOzone);
     }
     float const densityRayleigh = expX<LEAN>(divRX<LEAN>(-altitude, a.densityScaleRayleigh, a.rcpDsR));
     float const densityMie = expX<LEAN>(divRX<LEAN>(-altitude, a.densityScaleMie, a.rcpDsM));
-    return extinctionFromDensities<LEAN>(a, altitude, densityRayleigh, densityMie);
+    return extinctionFromDensities<LEAN>(a, altitude, densityRayleigh, densityMie, belowOzone);
 }
-template <bool LEAN> SZG_DEV Extinction extinctionFromDensities(const Atm& a, float altitude, float densityRayleigh, float densityMie)
+// belowOzone (wave-uniform, MarchSetup): every sample of the ray lies below 9.9 km, so altitude * 1000 - 25 <= -15.09 and the
+// test |h - 25 km| >= 15 km below holds at every step without being evaluated
+template <bool LEAN>
+SZG_DEV Extinction extinctionFromDensities(const Atm& a, float altitude, float densityRayleigh, float densityMie, bool belowOzone)
 {
     V3 const scatteringRayleigh = a.scatteringRayleigh * densityRayleigh;
     V3 const absorptionRayleigh = a.absorptionRayleigh * densityRayleigh;
@@ -523,6 +527,12 @@ template <bool LEAN> SZG_DEV Extinction extinctionFromDensities(const Atm& a, fl
     Extinction e;
     e.scatteringRayleigh = scatteringRayleigh;
     e.scatteringMie = scatteringMie;
+    if (LEAN && belowOzone && a.signClearCoefficients)
+    {
+        e.extinction = a.zeroAbsorptionRayleigh ? (scatteringRayleigh + scatteringMie)
+                                                : (((scatteringRayleigh + absorptionRayleigh) + scatteringMie) + absorptionMie);
+        return e;
+    }
     float const ozoneOffset = fabsf(altitude * 1000.0f - 25.0f);
     // Outside the ozone tent (|h - 25 km| >= 15 km) the density is max(0, 1 - q) with q >= 1, i.e. +0, and both ozone
     // products are +-0: adding them to a partial sum that is not -0 (sign-clear coefficients) changes nothing. When that holds for the whole wave (aerial-perspective marches
@@ -721,12 +731,16 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
     // only .rgb is consumed (common.glinl:111, :142): 12-byte loads keep 16 VGPRs per step out of flight
     const char* const base = reinterpret_cast<const char*>(L.texels);
     unsigned o00, o10, o01, o11; // byte offsets of the four texels
-    if (LEAN && INNER && waveAll(fu >= 0.0f && fu <= L.fwidth - 2.0f))
+    // (0 <= fu <= W - 2 as ONE unsigned compare of the converted index: a negative fu converts to a negative int = a huge
+    // unsigned, an fu beyond int range saturates to INT_MAX, and a NaN fu, which converts to 0, has NaN weights and gives
+    // a NaN texel average on either path)
+    unsigned const iu = (unsigned)(int)fu;
+    if (LEAN && INNER && waveAll(iu <= (unsigned)(L.width - 2)))
     {
         // interior column for the whole wave (the rule; the clamps only act for rays that point into the ground, x_mu > 1, or
         // on a rounding below 0): i0 = fu and i1 = fu + 1 are the unclamped indices and the right-hand texel of each row is
         // the next 16 bytes: one conversion and two full-rate adds instead of two clamps, two conversions and two shifts
-        unsigned const i0 = (unsigned)(int)fu;
+        unsigned const i0 = iu;
         o00 = (p.row0 + i0) << 4;
         o01 = (p.row1 + i0) << 4;
         o10 = o00 + 16u;
@@ -861,6 +875,11 @@ struct MarchSetup
     // ray from bounds (scatteringIntegral); the horizon smoothstep of sampleTransmittanceLUT_Sun is then exactly 1 at every
     // step and its operands (sin / cos of the horizon angle, the two edges) need not be formed
     bool sunClear;
+    // wave-uniform: every ray of the wave has a step dS >= 1e-7, so t = i * dS < 1e-7 (common.glinl:338) holds at step 0 and at
+    // no other step: the per-step comparison and its select are not needed
+    bool firstStepOnly;
+    // wave-uniform: every radius of the wave's rays is below Rp + 9.9 km (sampleExtinction's ozone tent is 0 there)
+    bool belowOzone;
     V3 T_origin;
 };
 
@@ -922,12 +941,12 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
             }
         }
 
-        Extinction const ex = sampleExtinction<LEAN, INNER>(a, altitude);
+        Extinction const ex = sampleExtinction<LEAN, INNER>(a, altitude, LEAN && m.belowOzone);
 
         // sampleTransmittanceLUT_RayMarchStep, common.glinl:336-361
         // (t < 1e-7 -> 1, common.glinl:338-341: true for the whole wave at step 0, where the tap and the quotients are skipped)
         V3 T_begin = splat(1.0f);
-        if (!waveAll(t < 0.0000001f))
+        if ((LEAN && m.firstStepOnly) ? (i != 0u) : !waveAll(t < 0.0000001f))
         {
             V3 const T_end = sampleT_at<LEAN, INNER>(L, a, pStep, xorSign(s_mu, m.up ? 0u : 0x80000000u));
             V3 ratio;
@@ -941,7 +960,7 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
                 ratio = clamp01(m.up ? (m.T_origin / T_end) : (T_end / m.T_origin));
             }
             // (only a wave with lanes on both sides of the threshold needs the per-lane select)
-            T_begin = waveAll(!(t < 0.0000001f)) ? ratio : ((t < 0.0000001f) ? splat(1.0f) : ratio);
+            T_begin = ((LEAN && m.firstStepOnly) || waveAll(!(t < 0.0000001f))) ? ratio : ((t < 0.0000001f) ? splat(1.0f) : ratio);
         }
 
         V3 const phaseTimesScattering = fma3(ex.scatteringMie, m.pM, ex.scatteringRayleigh * m.pR);
@@ -1031,6 +1050,11 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
                       m.sin_sunRadius >= 0x1p-30f && leanLength2(sun2) && leanLength2(direction2) && fabsf(mu) <= 2.0f &&
                       fabsf(mu_sun) <= 2.0f;
     m.extLean = waveAll(a.extModerate && rmin2 >= a.extFloor2 && fmaxf(m.r2, L2) <= a.extCeil2);
+    m.firstStepOnly = waveAll(lean && m.dS >= 0.0000001f); // then fl(i * dS) >= dS >= 1e-7 for every i >= 1
+    {
+        float const ozoneLow = a.planetRadius + 0.0099f; // Mm: below the 10 km foot of the tent (25 km - 15 km) with a margin
+        m.belowOzone = waveAll(lean && fmaxf(m.r2, L2) <= ozoneLow * ozoneLow);
+    }
     // sunClear. At step i the sun cosine handed to the smoothstep is s_musun = (r_musun + t * mu_sunAndStep) / s_radius with
     // t >= 0 and mu_sunAndStep >= 0 (a safeSqrt), so its numerator is >= r_musun, and s_radius is the radius of a point of
     // the segment: <= sqrt(max(r2, L2)) up to rounding. The test passes when s_musun >= cos_hz cos R + sin_hz sin R, and with
