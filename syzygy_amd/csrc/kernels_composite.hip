@@ -136,7 +136,8 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
                                                    unsigned cameraIndex,
                                                    const szg_directional_light_packed* __restrict__ dirLights,
                                                    unsigned sunLightIndex, const float4* __restrict__ tlut, int tW, int tH,
-                                                   const float4* __restrict__ slut, int sW, int sH, AerialLut aerial)
+                                                   const float4* __restrict__ slut, int sW, int sH, AerialLut aerial,
+                                                   const FramePrep* __restrict__ prep)
 {
     unsigned const tid = threadIdx.x;
     unsigned const wave = tid >> 6, lane = tid & 63u;
@@ -148,8 +149,8 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
     }
     unsigned const gy = global_row(rm, y);
 
-    Atm const a = load_atm(atmospheres + atmosphereIndex);
-    TLut const L = make_tlut(tlut, tW, tH);
+    Atm const a = load_atm(*prep); // (k_frame_prep: load_atm(atmospheres + atmosphereIndex), once per frame instead of once per wave)
+    TLut const L = make_tlut(tlut, tW, tH, *prep);
     SkyLut const S{slut, sW, sH, reinterpret_cast<const unsigned*>(slut + (size_t)sW * (size_t)sH)[0] == 0u};
     const szg_camera_packed* cam = cameras + cameraIndex;
 
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
 hipError_t launch_composite(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
                             const szg_gbuffer& g, ShadowSlot sunSlot, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                             unsigned camIndex, const szg_directional_light_packed* d_dir, unsigned sunIndex, const float* tlut,
-                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH, AerialLut aerial)
+                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH, AerialLut aerial, const void* d_prep)
 {
     unsigned const rows = tile.nranks <= 1u ? drawH : tile.local_rows;
     if (rows == 0u || drawW == 0u)
@@ -404,14 +405,14 @@ hipError_t launch_composite(hipStream_t s, const szg_scene_texture& scene, unsig
         hipLaunchKernelGGL(k_composite<true>, grid, dim3(256), 0, s, scene.color, scene.depth, scene.debug_color, gp, drawW, drawH,
                            rows, rm, sunSlot, d_atm, atmIndex, d_cam, camIndex, d_dir, sunIndex,
                            reinterpret_cast<const float4*>(tlut), (int)tW, (int)tH, reinterpret_cast<const float4*>(slut),
-                           (int)sW, (int)sH, aerial);
+                           (int)sW, (int)sH, aerial, static_cast<const FramePrep*>(d_prep));
     }
     else
     {
         hipLaunchKernelGGL(k_composite<false>, grid, dim3(256), 0, s, scene.color, scene.depth, scene.debug_color, gp, drawW, drawH,
                            rows, rm, sunSlot, d_atm, atmIndex, d_cam, camIndex, d_dir, sunIndex,
                            reinterpret_cast<const float4*>(tlut), (int)tW, (int)tH, reinterpret_cast<const float4*>(slut),
-                           (int)sW, (int)sH, aerial);
+                           (int)sW, (int)sH, aerial, static_cast<const FramePrep*>(d_prep));
     }
     return hipGetLastError();
 }

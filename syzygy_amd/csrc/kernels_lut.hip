@@ -140,12 +140,32 @@ __global__ __launch_bounds__(256) void k_lut_range(float4* __restrict__ lut, uns
     }
 }
 
+// One lane: the per-frame constants of szg_device.hpp FramePrep.
+__global__ __launch_bounds__(64) void k_frame_prep(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
+                                                   int tW, int tH, FramePrep* __restrict__ out)
+{
+    if (threadIdx.x != 0u)
+    {
+        return;
+    }
+    FramePrep f;
+    f.a = load_atm(atmospheres + atmosphereIndex);
+    f.fwidth = (float)tW;
+    f.fheight = (float)tH;
+    f.u_bias = 0.5f / (float)tW;
+    f.u_scale = 1.0f - 1.0f / (float)tW;
+    f.v_bias = 0.5f / (float)tH;
+    f.v_scale = 1.0f - 1.0f / (float)tH;
+    *out = f;
+}
+
 // 256-thread workgroups covering 32x8 texels (each wave an 8x8 patch, so the
 // four transmittance-LUT taps of neighbouring lanes share cache lines).
 __global__ __launch_bounds__(256, 4) void k_skyview(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
                                                  const szg_camera_packed* __restrict__ cameras, unsigned cameraIndex,
                                                  const float4* __restrict__ tlut, int tW, int tH, float4* __restrict__ lut,
-                                                 int W, int H, int rowBegin, int rowEnd, const unsigned* __restrict__ dirty)
+                                                 int W, int H, int rowBegin, int rowEnd, const unsigned* __restrict__ dirty,
+                                                 const FramePrep* __restrict__ prep)
 {
     if (dirty != nullptr && dirty[0] == 0u) // LUT reuse: inputs unchanged since these texels were computed
     {
@@ -159,8 +179,8 @@ __global__ __launch_bounds__(256, 4) void k_skyview(const szg_atmosphere_packed*
     {
         return;
     }
-    Atm const a = load_atm(atmospheres + atmosphereIndex);
-    TLut const L = make_tlut(tlut, tW, tH);
+    Atm const a = load_atm(*prep); // (k_frame_prep: load_atm(atmospheres + atmosphereIndex), once per frame instead of once per wave)
+    TLut const L = make_tlut(tlut, tW, tH, *prep);
     const szg_camera_packed* cam = cameras + cameraIndex;
     float const PI = 3.141592653589793f;
 
@@ -452,6 +472,13 @@ hipError_t launch_lut_key(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
     return hipGetLastError();
 }
 
+size_t frame_prep_bytes() { return sizeof(FramePrep); }
+hipError_t launch_frame_prep(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, unsigned tW, unsigned tH, void* d_prep)
+{
+    hipLaunchKernelGGL(k_frame_prep, dim3(1), dim3(64), 0, s, d_atm, atmIndex, (int)tW, (int)tH, static_cast<FramePrep*>(d_prep));
+    return hipGetLastError();
+}
+
 hipError_t launch_lut_range(hipStream_t s, float* lut, unsigned W, unsigned H)
 {
     unsigned const n = W * H;
@@ -478,7 +505,7 @@ hipError_t launch_slut_check(hipStream_t s, float* lut, unsigned W, unsigned H)
 
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
-                          unsigned rowBegin, unsigned rowEnd, const unsigned* d_dirty)
+                          unsigned rowBegin, unsigned rowEnd, const unsigned* d_dirty, const void* d_prep)
 {
     if (rowEnd > H)
     {
@@ -500,7 +527,8 @@ hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
     }
     dim3 const grid((W + 31u) / 32u, (rowEnd - rowBegin + 7u) / 8u);
     hipLaunchKernelGGL(k_skyview, grid, dim3(256), 0, s, d_atm, atmIndex, d_cam, camIndex, reinterpret_cast<const float4*>(tlut),
-                       (int)tW, (int)tH, reinterpret_cast<float4*>(lut), (int)W, (int)H, (int)rowBegin, (int)rowEnd, d_dirty);
+                       (int)tW, (int)tH, reinterpret_cast<float4*>(lut), (int)W, (int)H, (int)rowBegin, (int)rowEnd, d_dirty,
+                       static_cast<const FramePrep*>(d_prep));
     return hipGetLastError();
 }
 } // namespace szg

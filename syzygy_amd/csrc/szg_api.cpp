@@ -300,6 +300,10 @@ struct szg_skyview
     // LUT reuse across frames (szg_launch.hpp "LUT reuse"; off by default = the reference's recompute-every-frame)
     bool lutReuse = false;
     unsigned* d_lutKey = nullptr;                      // LUT_KEY_DWORDS dwords of device state
+    // szg::frame_prep_bytes() each: per-frame constants (k_frame_prep), one block per pass, because a caller may record the
+    // LUT pass of frame k+1 on another stream than the composite of frame k (rowtile.py does)
+    void* d_framePrep = nullptr;     // sky-view LUT pass
+    void* d_framePrepDraw = nullptr; // composite
     mutable bool forceTransmittance = true, forceSkyview = true; // the host knows the texels are stale
 };
 
@@ -457,6 +461,14 @@ int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int de
     {
         e = hipMemset(p->d_lutKey, 0, szg::LUT_KEY_DWORDS * sizeof(unsigned));
     }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(&p->d_framePrep, szg::frame_prep_bytes());
+    }
+    if (e == hipSuccess)
+    {
+        e = hipMalloc(&p->d_framePrepDraw, szg::frame_prep_bytes());
+    }
     if (e != hipSuccess)
     {
         szg_skyview_destroy(p);
@@ -529,6 +541,14 @@ void szg_skyview_destroy(szg_skyview_t* p)
     if (p->d_lutKey != nullptr)
     {
         (void)hipFree(p->d_lutKey);
+    }
+    if (p->d_framePrep != nullptr)
+    {
+        (void)hipFree(p->d_framePrep);
+    }
+    if (p->d_framePrepDraw != nullptr)
+    {
+        (void)hipFree(p->d_framePrepDraw);
     }
     delete p;
 }
@@ -607,9 +627,11 @@ int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t
                                     p->d_skyview, p->desc.skyview_width, p->desc.skyview_height));
         dirty = p->d_lutKey + 70;
     }
+    SZG_HIP(szg::launch_frame_prep(s, d_atmospheres, atmosphere_index, p->desc.transmittance_width, p->desc.transmittance_height,
+                                   p->d_framePrep));
     SZG_HIP(szg::launch_skyview(s, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, p->d_transmittance,
                                 p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview, p->desc.skyview_width,
-                                p->desc.skyview_height, row_begin, row_end, dirty));
+                                p->desc.skyview_height, row_begin, row_end, dirty, p->d_framePrep));
     p->haveSkyview = true;
     // a launch over all rows leaves the status dword behind the texels right; a slice does not know the other rows
     p->slutStatusValid = whole;
@@ -722,10 +744,12 @@ static int record_composite(szg_skyview_t* p, void* stream, const szg_scene_text
     }
     SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(ensure_slut_status(p, static_cast<hipStream_t>(stream)));
+    SZG_HIP(szg::launch_frame_prep(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, p->desc.transmittance_width,
+                                   p->desc.transmittance_height, p->d_framePrepDraw));
     SZG_HIP(szg::launch_composite(static_cast<hipStream_t>(stream), *scene_texture, draw_rect.width, draw_rect.height, t, *gbuffer,
                                   sun, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, d_lights, sun_light_index,
                                   p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,
-                                  p->desc.skyview_width, p->desc.skyview_height, aerial));
+                                  p->desc.skyview_width, p->desc.skyview_height, aerial, p->d_framePrepDraw));
     return SZG_OK;
 }
 

@@ -640,6 +640,68 @@ SZG_DEV TLut make_tlut(const float4* texels, int w, int h)
     return t;
 }
 
+// Per-frame constants (k_frame_prep, one lane, launched in front of the composite and the sky-view LUT kernel): everything
+// load_atm() and make_tlut() derive from the atmosphere block and the LUT extent - ~300 instructions that every wave of
+// those kernels would otherwise repeat - computed once and read back through scalar loads. Same code, same values.
+struct FramePrep
+{
+    Atm a;
+    float fwidth, fheight, u_bias, u_scale, v_bias, v_scale;
+};
+// The block arrives through scalar loads; its floats then move to vector registers, where the per-wave derivation used to
+// leave them: a VALU instruction of gfx950 reads at most one scalar operand, and ~70 constants held in scalar registers
+// through the march loops spill (v_writelane / v_readlane inside the loops). The flags stay scalar: they steer wave-uniform
+// branches.
+SZG_DEV float inVector(float x)
+{
+    asm volatile("" : "+v"(x));
+    return x;
+}
+SZG_DEV V3 inVector(V3 v) { return V3{inVector(v.x), inVector(v.y), inVector(v.z)}; }
+SZG_DEV Atm load_atm(const FramePrep& f)
+{
+    Atm a = f.a;
+    a.scatteringRayleigh = inVector(a.scatteringRayleigh);
+    a.densityScaleRayleigh = inVector(a.densityScaleRayleigh);
+    a.absorptionRayleigh = inVector(a.absorptionRayleigh);
+    a.planetRadius = inVector(a.planetRadius);
+    a.scatteringMie = inVector(a.scatteringMie);
+    a.densityScaleMie = inVector(a.densityScaleMie);
+    a.atmosphereRadius = inVector(a.atmosphereRadius);
+    a.incidentDirectionSun = inVector(a.incidentDirectionSun);
+    a.scatteringOzone = inVector(a.scatteringOzone);
+    a.absorptionOzone = inVector(a.absorptionOzone);
+    a.sunIntensitySpectrum = inVector(a.sunIntensitySpectrum);
+    a.sunAngularRadius = inVector(a.sunAngularRadius);
+    a.Ra2 = inVector(a.Ra2);
+    a.Rp2 = inVector(a.Rp2);
+    a.H = inVector(a.H);
+    a.rcpH = inVector(a.rcpH);
+    a.rcpDsR = inVector(a.rcpDsR);
+    a.rcpDsM = inVector(a.rcpDsM);
+    a.rcp15 = inVector(a.rcp15);
+    a.leanFloor2 = inVector(a.leanFloor2);
+    a.extFloor2 = inVector(a.extFloor2);
+    a.extCeil2 = inVector(a.extCeil2);
+    a.innerCeil2 = inVector(a.innerCeil2);
+    return a;
+}
+SZG_DEV TLut make_tlut(const float4* texels, int w, int h, const FramePrep& f)
+{
+    TLut t;
+    t.moderate = reinterpret_cast<const unsigned*>(texels + (size_t)w * (size_t)h)[0] == 0u;
+    t.texels = texels;
+    t.width = w;
+    t.height = h;
+    t.fwidth = inVector(f.fwidth);
+    t.fheight = inVector(f.fheight);
+    t.u_bias = inVector(f.u_bias);
+    t.u_scale = inVector(f.u_scale);
+    t.v_bias = inVector(f.v_bias);
+    t.v_scale = inVector(f.v_scale);
+    return t;
+}
+
 SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float fW, float fH, float s, float t)
 {
     float const u = __builtin_fmaf(s, fW, -0.5f);

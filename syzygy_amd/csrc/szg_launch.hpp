@@ -77,7 +77,11 @@ inline size_t slut_block_bytes(unsigned W, unsigned H) { return (size_t)W * H * 
 hipError_t launch_slut_check(hipStream_t s, float* lut, unsigned W, unsigned H);
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
-                          unsigned rowBegin, unsigned rowEnd, const unsigned* d_dirty = nullptr);
+                          unsigned rowBegin, unsigned rowEnd, const unsigned* d_dirty, const void* d_prep);
+// Per-frame constants (szg_device.hpp FramePrep): one-lane kernel in front of the sky-view LUT kernel and the composite, which
+// read `d_prep` (frame_prep_bytes() bytes of device memory) instead of deriving the same ~300 instructions' worth in every wave.
+size_t frame_prep_bytes();
+hipError_t launch_frame_prep(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, unsigned tW, unsigned tH, void* d_prep);
 hipError_t launch_light_prep(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount, unsigned dirSkip,
                              const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_slots,
                              unsigned slotCount, LightRec* d_out);
@@ -91,7 +95,7 @@ hipError_t launch_gbuffer_fill(hipStream_t s, const szg_scene_texture& scene, un
 hipError_t launch_composite(hipStream_t s, const szg_scene_texture& scene, unsigned drawW, unsigned drawH, TileArgs tile,
                             const szg_gbuffer& g, ShadowSlot sunSlot, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                             unsigned camIndex, const szg_directional_light_packed* d_dir, unsigned sunIndex, const float* tlut,
-                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH, AerialLut aerial);
+                            unsigned tW, unsigned tH, const float* slut, unsigned sW, unsigned sH, AerialLut aerial, const void* d_prep);
 hipError_t launch_aerial_lut(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                              unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* luminance, float* transmittance,
                              unsigned W, unsigned H, unsigned D, float maxDistance);
