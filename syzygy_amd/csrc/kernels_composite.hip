@@ -142,7 +142,9 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
     unsigned const tid = threadIdx.x;
     unsigned const wave = tid >> 6, lane = tid & 63u;
     unsigned const x = blockIdx.x * 32u + wave * 8u + (lane & 7u);
-    unsigned const y = blockIdx.y * 8u + (lane >> 3);
+    // Workgroups are dispatched in blockIdx order; the rows are walked from the bottom of the image upwards so that the
+    // cheap workgroups (sky: no march) tend to come last and fill the tail of the launch instead of its start.
+    unsigned const y = (gridDim.y - 1u - blockIdx.y) * 8u + (lane >> 3);
     if (x >= drawW || y >= localRows)
     {
         return;

@@ -24,6 +24,15 @@ SZG_DEV void pixel_of_thread(unsigned& x, unsigned& y)
     x = blockIdx.x * 32u + wave * 8u + (lane & 7u);
     y = blockIdx.y * 8u + (lane >> 3);
 }
+// The same tiling with the rows walked from the bottom of the image upwards (workgroups are dispatched in blockIdx order):
+// the cheap workgroups - background texels, at the top of most frames - then come last and fill the tail of the launch.
+SZG_DEV void pixel_of_thread_bottom_up(unsigned& x, unsigned& y)
+{
+    unsigned const tid = threadIdx.x;
+    unsigned const wave = tid >> 6, lane = tid & 63u;
+    x = blockIdx.x * 32u + wave * 8u + (lane & 7u);
+    y = (gridDim.y - 1u - blockIdx.y) * 8u + (lane >> 3);
+}
 
 template <typename T> SZG_DEV T* row_ptr(const szg_image& im, unsigned y)
 {
@@ -440,7 +449,7 @@ __global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug
                                                 unsigned cameraIndex, const LightRec* __restrict__ lights, unsigned lightCount)
 {
     unsigned x, y;
-    pixel_of_thread(x, y);
+    pixel_of_thread_bottom_up(x, y);
     if (x >= drawW || y >= localRows)
     {
         return;
