@@ -392,6 +392,45 @@ def test_full_frame_chain_matches_oracle(gpu, elevation):
     assert rel.max() <= RTOL
 
 
+def test_full_frame_chain_with_nonzero_buffer_indices(gpu):
+    """The reference addresses its parameter blocks as buffer[index] (atmosphereIndex, cameraIndex, sunLightIndex and the
+    directional-light skip count of the push constants: skyview.hpp:64-144, deferred.hpp:82-98). Every other test uses
+    index 0; here the blocks in use sit at atmosphere 2 of 3, camera 1 of 3 and lights [poison, sun, moon] with the sun at
+    index 1 and a skip count of 2, and every unused slot is filled with 0xFF bytes (NaN): the frame must equal the frame
+    rendered from the plain buffers bit for bit, and the oracle's."""
+    pl, abi = gpu.pl, gpu.abi
+    inp = util.Inputs(200, 120, elevation_degrees=25.0, spots=6)
+
+    def poison(ctype):
+        v = ctype()
+        C.memset(C.byref(v), 0xFF, C.sizeof(v))
+        return v
+
+    cameras = pl.TStagedBuffer(abi.CameraPacked, 3)
+    atmospheres = pl.TStagedBuffer(abi.AtmospherePacked, 3)
+    lights = pl.TStagedBuffer(abi.DirectionalLightPacked, 3)
+    cameras.push([poison(abi.CameraPacked), inp.cam, poison(abi.CameraPacked)])
+    atmospheres.push([poison(abi.AtmospherePacked), poison(abi.AtmospherePacked), inp.atm])
+    lights.push([poison(abi.DirectionalLightPacked), inp.sun, inp.moon])
+    for b in (cameras, atmospheres, lights):
+        b.recordCopyToDevice()
+    target = pl.SceneTexture(inp.width, inp.height, debug=True)
+    deferred = pl.DeferredShadingPipeline((inp.width, inp.height), max_spot_lights=inp.spot_count, max_shadow_maps=0)
+    sky = pl.SkyViewComputePipeline.create(transmittance_extent=(512, 128), skyview_extent=(512, 256))
+    deferred.recordDrawCommands(None, inp.rect, target, 2, lights, inp.spots, 1, cameras, inp.synthetic.fill)
+    sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 2, atmospheres, 1, cameras, 1, lights)
+    torch.cuda.synchronize()
+    got, got_q = target.debug.cpu().numpy(), target.color_numpy()
+    deferred.cleanup()
+    sky.destroy()
+    plain, plain_q = render_gpu(gpu, inp)
+    assert np.array_equal(got_q, plain_q)
+    assert np.array_equal(got.view(np.uint32), plain.view(np.uint32))
+    frame = render_oracle(gpu, inp)
+    assert np.abs(got_q.astype(np.int32) - frame.color.astype(np.int32)).max() <= 1
+    assert util.rel_err(got[..., :3], frame.debug[..., :3], util.ATOL_COLOR).max() <= RTOL
+
+
 # ---------------------------------------------------------------------------
 # inputs outside the domain of the lean exact ops: the kernels must take their generic code path
 # (szg_device.hpp leanAtmosphere / leanRay) and still match the oracle
