@@ -76,6 +76,8 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # (dmabuf IPC is the only kind this pool's host driver supports; RCCL needs it before the first HIP call of a rank)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

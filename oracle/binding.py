@@ -14,6 +14,7 @@ from syzygy_amd import abi
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 _LIBM = None
+_LITERAL = None
 
 VP = C.c_void_p
 U32 = C.c_uint32
@@ -79,6 +80,29 @@ def lib_libm():
     if _LIBM is None:
         _LIBM = _load("libszg_oracle_libm.so")
     return _LIBM
+
+
+def lib_literal():
+    """The oracle with its contraction rule switched off (-DSZG_ORACLE_LITERAL): what tests/test_spirv_pin.py compares with
+    the literal execution of the reference's SPIR-V."""
+    global _LITERAL
+    if _LITERAL is None:
+        _LITERAL = _load("libszg_oracle_literal.so")
+    return _LITERAL
+
+
+class use_literal:
+    """Context manager: route the module-level helpers to the literal (uncontracted) build."""
+
+    def __enter__(self):
+        global _LIB
+        self._saved = lib()
+        _LIB = lib_literal()
+
+    def __exit__(self, *a):
+        global _LIB
+        _LIB = self._saved
+        return False
 
 
 class use_libm:

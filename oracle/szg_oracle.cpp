@@ -9,11 +9,15 @@
 // PARITY PINNING: the reference holds no golden vectors, known-answer tests or
 // fixtures for this path and its shaders cannot be compiled or
 // run here (GLSL + Vulkan 1.3; glslang/Vulkan/glm absent, FetchContent needs a
-// network). So this oracle is pinned by (a) line-by-line review against the
-// files cited at every function, (b) closed-form anchors and structural
-// properties checked in tests/test_oracle.py (zenith optical depth, uv<->(r,mu)
-// round trip, top-of-atmosphere T=1, light linearity, sky-view mirror symmetry)
-// — i.e. "parity unpinned by reference tests"; see DESIGN.md.
+// network). It does hold the COMPILED shaders: since round 2 this oracle is
+// pinned against them (tests/test_spirv_pin.py, see PINNING below: the
+// committed SPIR-V executed literally by an interpreter written here, equal
+// to this file's literal build bit for bit), besides (a) line-by-line review
+// against the files cited at every function and (b) closed-form anchors and
+// structural properties checked in tests/test_oracle.py (zenith optical depth,
+// uv<->(r,mu) round trip, top-of-atmosphere T=1, light linearity, sky-view
+// mirror symmetry). The implementation-defined parts (built-ins, texture
+// filter, UNORM conversion, contraction) are conventions, not pins; DESIGN.md 2.
 //
 // Numerics: every GLSL operation is evaluated in fp32 in the order written in
 // the shader; compile with -O2 -ffp-contract=off (the COMPILER contracts
@@ -45,6 +49,19 @@
 // =============================================================================
 
 #include "szg/abi.h"
+
+// PINNING. tests/test_spirv_pin.py: the -DSZG_ORACLE_LITERAL build of this file reproduces, bit for bit, 64 + 84 LUT
+// texels and 582 + 582 pixels that tests/golden/spirv_interp.py obtained by executing the reference's COMMITTED SPIR-V
+// (transmittance_LUT / skyview_LUT / lights / camera .comp.spv) literally. Outside that pin: the values of the built-ins
+// below, the sampler / UNORM models and the contraction rule - the freedoms Vulkan leaves to an implementation.
+// The contraction rule as ONE switch: -DSZG_ORACLE_LITERAL evaluates every a * b + c of the list above with two roundings,
+// i.e. executes the shaders' SPIR-V literally (libszg_oracle_literal.so; tests/test_spirv_pin.py compares that build, bit for
+// bit, with an interpreter run over the reference's committed .spv). The default build fuses.
+#ifdef SZG_ORACLE_LITERAL
+#define SZG_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define SZG_FMA(a, b, c) fmaf((a), (b), (c))
+#endif
 
 // GLSL built-ins: by default the pinned fp32 algorithms of szg/fpmath.h (so that oracle
 // and GPU kernels are reproducible bit for bit); with -DSZG_ORACLE_LIBM the correctly
@@ -99,7 +116,7 @@ struct vec4
 inline vec2 operator+(vec2 a, vec2 b) { return {a.x + b.x, a.y + b.y}; }
 inline vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
 inline vec2 operator*(vec2 a, float s) { return {a.x * s, a.y * s}; }
-inline float dot(vec2 a, vec2 b) { return fmaf(a.y, b.y, a.x * b.x); } // OpDot: contraction rule, file header
+inline float dot(vec2 a, vec2 b) { return SZG_FMA(a.y, b.y, a.x * b.x); } // OpDot: contraction rule, file header
 
 inline vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -121,7 +138,7 @@ inline vec3& operator*=(vec3& a, vec3 b)
     return a;
 }
 
-inline float dot(vec3 a, vec3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); } // OpDot
+inline float dot(vec3 a, vec3 b) { return SZG_FMA(a.z, b.z, SZG_FMA(a.y, b.y, a.x * b.x)); } // OpDot
 inline float length(vec3 a) { return sqrtf(dot(a, a)); }
 inline float length(vec2 a) { return sqrtf(dot(a, a)); }
 inline float distance(vec3 a, vec3 b) { return length(a - b); }
@@ -135,13 +152,13 @@ inline vec3 clamp(vec3 v, float lo, float hi) { return {clampf(v.x, lo, hi), cla
 // mix(a, b, w) = a*(1-w) + b*w
 inline vec3 mix(vec3 a, vec3 b, vec3 w)
 {
-    return {fmaf(b.x, w.x, a.x * (1.0f - w.x)), fmaf(b.y, w.y, a.y * (1.0f - w.y)), fmaf(b.z, w.z, a.z * (1.0f - w.z))};
+    return {SZG_FMA(b.x, w.x, a.x * (1.0f - w.x)), SZG_FMA(b.y, w.y, a.y * (1.0f - w.y)), SZG_FMA(b.z, w.z, a.z * (1.0f - w.z))};
 }
 inline vec3 mix(vec3 a, vec3 b, float w) { return mix(a, b, vec3(w)); }
 // contracted forms of  a * s + c,  a * b + c  and  c - t * d  (one rounding per component)
-inline vec3 fma3(vec3 a, float s, vec3 c) { return {fmaf(a.x, s, c.x), fmaf(a.y, s, c.y), fmaf(a.z, s, c.z)}; }
-inline vec3 fma3(vec3 a, vec3 b, vec3 c) { return {fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z)}; }
-inline vec3 fnma(float t, vec3 d, vec3 c) { return {fmaf(-t, d.x, c.x), fmaf(-t, d.y, c.y), fmaf(-t, d.z, c.z)}; }
+inline vec3 fma3(vec3 a, float s, vec3 c) { return {SZG_FMA(a.x, s, c.x), SZG_FMA(a.y, s, c.y), SZG_FMA(a.z, s, c.z)}; }
+inline vec3 fma3(vec3 a, vec3 b, vec3 c) { return {SZG_FMA(a.x, b.x, c.x), SZG_FMA(a.y, b.y, c.y), SZG_FMA(a.z, b.z, c.z)}; }
+inline vec3 fnma(float t, vec3 d, vec3 c) { return {SZG_FMA(-t, d.x, c.x), SZG_FMA(-t, d.y, c.y), SZG_FMA(-t, d.z, c.z)}; }
 inline float smoothstep(float e0, float e1, float x)
 {
     float const t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
@@ -164,10 +181,10 @@ inline mat4 load(const szg_mat4& s)
 inline vec4 operator*(const mat4& a, vec4 v)
 {
     vec4 r;
-    r.x = fmaf(a.m[12], v.w, fmaf(a.m[8], v.z, fmaf(a.m[4], v.y, a.m[0] * v.x)));
-    r.y = fmaf(a.m[13], v.w, fmaf(a.m[9], v.z, fmaf(a.m[5], v.y, a.m[1] * v.x)));
-    r.z = fmaf(a.m[14], v.w, fmaf(a.m[10], v.z, fmaf(a.m[6], v.y, a.m[2] * v.x)));
-    r.w = fmaf(a.m[15], v.w, fmaf(a.m[11], v.z, fmaf(a.m[7], v.y, a.m[3] * v.x)));
+    r.x = SZG_FMA(a.m[12], v.w, SZG_FMA(a.m[8], v.z, SZG_FMA(a.m[4], v.y, a.m[0] * v.x)));
+    r.y = SZG_FMA(a.m[13], v.w, SZG_FMA(a.m[9], v.z, SZG_FMA(a.m[5], v.y, a.m[1] * v.x)));
+    r.z = SZG_FMA(a.m[14], v.w, SZG_FMA(a.m[10], v.z, SZG_FMA(a.m[6], v.y, a.m[2] * v.x)));
+    r.w = SZG_FMA(a.m[15], v.w, SZG_FMA(a.m[11], v.z, SZG_FMA(a.m[7], v.y, a.m[3] * v.x)));
     return r;
 }
 // glm's mat4 * mat4 as HOST code evaluates it: one rounding per operation (for matrices the reference computes on the CPU)
@@ -343,8 +360,8 @@ inline float sample_depth_border(const Image& im, vec2 uv)
 // texture() LINEAR / CLAMP_TO_EDGE, no mips, fp32 weights (skyview.cpp:199-207, :339-346)
 inline vec3 sample_linear_rgb(const Image& im, vec2 st)
 {
-    float const u = fmaf(st.x, (float)im.width, -0.5f);
-    float const v = fmaf(st.y, (float)im.height, -0.5f);
+    float const u = SZG_FMA(st.x, (float)im.width, -0.5f);
+    float const v = SZG_FMA(st.y, (float)im.height, -0.5f);
     float const fu = floorf(u);
     float const fv = floorf(v);
     float const a = u - fu;
@@ -365,9 +382,9 @@ inline vec3 sample_linear_rgb(const Image& im, vec2 st)
     float const w01 = (1.0f - a) * b;
     float const w11 = a * b;
     vec3 r;
-    r.x = fmaf(w11, t11.x, fmaf(w01, t01.x, fmaf(w10, t10.x, w00 * t00.x)));
-    r.y = fmaf(w11, t11.y, fmaf(w01, t01.y, fmaf(w10, t10.y, w00 * t00.y)));
-    r.z = fmaf(w11, t11.z, fmaf(w01, t01.z, fmaf(w10, t10.z, w00 * t00.z)));
+    r.x = SZG_FMA(w11, t11.x, SZG_FMA(w01, t01.x, SZG_FMA(w10, t10.x, w00 * t00.x)));
+    r.y = SZG_FMA(w11, t11.y, SZG_FMA(w01, t01.y, SZG_FMA(w10, t10.y, w00 * t00.y)));
+    r.z = SZG_FMA(w11, t11.z, SZG_FMA(w01, t01.z, SZG_FMA(w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -428,7 +445,7 @@ inline float safeSqrt(float value) { return sqrtf(fmaxf(value, 0.0f)); }
 // common.glinl:29-32
 inline float textureCoordFromUnitRange(float value, int dimension)
 {
-    return fmaf(value, 1.0f - 1.0f / (float)dimension, 0.5f / (float)dimension);
+    return SZG_FMA(value, 1.0f - 1.0f / (float)dimension, 0.5f / (float)dimension);
 }
 // common.glinl:33-36
 inline float unitRangeFromTextureCoord(float texCoord, int dimension)
@@ -443,7 +460,7 @@ vec2 transmittanceLUT_RMu_to_UV(const Atmosphere& atmosphere, const Transmittanc
     float const planetRadiusMmSquared = atmosphere.planetRadiusMm * atmosphere.planetRadiusMm;
     float const H = safeSqrt(atmospherRadiusMmSquared - planetRadiusMmSquared);
     float const rho = safeSqrt(radius * radius - planetRadiusMmSquared);
-    float const d = fmaxf(fmaf(-radius, mu, safeSqrt(fmaf(radius * radius, fmaf(mu, mu, -1.0f), atmospherRadiusMmSquared))), 0.0f);
+    float const d = fmaxf(SZG_FMA(-radius, mu, safeSqrt(SZG_FMA(radius * radius, SZG_FMA(mu, mu, -1.0f), atmospherRadiusMmSquared))), 0.0f);
     float const d_min = atmosphere.atmosphereRadiusMm - radius;
     float const d_max = rho + H;
     float const x_mu = (d - d_min) / (d_max - d_min);
@@ -646,9 +663,9 @@ RaymarchStep stepRadiusMu(RaymarchStep start, float stepDistance)
         safeSqrt(start.mu_sun * start.mu - safeSqrt((1.0f - start.mu_sun * start.mu_sun) * (1.0f - start.mu * start.mu)));
     RaymarchStep result;
     result.radius =
-        safeSqrt(fmaf(2.0f * start.radius * start.mu, stepDistance, stepDistance * stepDistance) + start.radius * start.radius);
+        safeSqrt(SZG_FMA(2.0f * start.radius * start.mu, stepDistance, stepDistance * stepDistance) + start.radius * start.radius);
     result.mu = (start.radius * start.mu + stepDistance) / result.radius;
-    result.mu_sun = fmaf(stepDistance, mu_sunAndStepDirection, start.radius * start.mu_sun) / result.radius;
+    result.mu_sun = SZG_FMA(stepDistance, mu_sunAndStepDirection, start.radius * start.mu_sun) / result.radius;
     return result;
 }
 

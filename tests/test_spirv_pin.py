@@ -1,0 +1,163 @@
+"""The oracle pinned against the reference's own shader binaries.
+
+tests/golden/spirv_vectors.npz holds the outputs of the COMMITTED SPIR-V of transmittance_LUT.comp, skyview_LUT.comp,
+lights.comp and camera.comp, executed literally (one IEEE binary32 operation per SPIR-V arithmetic instruction, in program
+order) by the interpreter of tests/golden/spirv_interp.py on seeded inputs, together with those inputs
+(tests/golden/make_spirv_vectors.py wrote it in the build container, where the reference checkout is; the .spv files
+themselves are not in this repository).
+
+What is asserted: the oracle with its contraction rule switched off (oracle/libszg_oracle_literal.so: the same source,
+-DSZG_ORACLE_LITERAL turns every fused a * b + c of the rule into two roundings) reproduces every vector BIT FOR BIT. So the
+restatement performs the shader's operations, with the shader's constants, in the shader's order, on every path these vectors
+walk (sky, sun disc, ground hits, lit and unlit geometry, reflections, all three light types, PCF shadow taps, both LUT
+kernels). The default oracle - the parity checker of the GPU tests - differs from the literal one only by the documented
+contraction rule (oracle/szg_oracle.cpp header), a freedom the SPIR-V grants (no NoContraction decoration).
+
+Not pinned, because Vulkan leaves them to the implementation: the values of exp / pow / sin / cos / asin / acos
+(both sides use include/szg/fpmath.h), the texture filter and UNORM conversion models, and where a real GPU contracts.
+"""
+import ctypes as C
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from oracle import binding as ob
+from syzygy_amd import abi
+from tests.golden import make_spirv_vectors as gen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def vec():
+    return np.load(os.path.join(ROOT, "tests", "golden", "spirv_vectors.npz"))
+
+
+_TLUTS = {}
+
+
+def _tlut(vec, k):
+    """The 512 x 128 transmittance LUT of scenario k: recomputed by the literal oracle (its texels are what
+    test_transmittance_lut_shader pins), and required to be the array the vectors were made with."""
+    if k not in _TLUTS:
+        atm = _block(abi.AtmospherePacked, vec[f"atm_{k}"])
+        with ob.use_literal():
+            t = ob.transmittance_lut(atm, 512, 128, threads=8)
+        assert hashlib.sha256(t.tobytes()).digest() == bytes(vec[f"tlut_sha256_{k}"]), "the transmittance LUT changed"
+        _TLUTS[k] = t
+    return _TLUTS[k]
+
+
+def _block(ctype, raw):
+    return ctype.from_buffer_copy(bytes(np.ascontiguousarray(raw, np.uint8)))
+
+
+def _array(ctype, raw):
+    raw = bytes(np.ascontiguousarray(raw, np.uint8))
+    n = len(raw) // C.sizeof(ctype)
+    return (ctype * n).from_buffer_copy(raw), n
+
+
+def _same(got, want_bits, what):
+    got_bits = np.ascontiguousarray(got, np.float32).view(np.uint32)
+    bad = np.argwhere(got_bits != want_bits)
+    assert bad.size == 0, (what, len(bad), bad[:5].tolist(), np.asarray(got)[tuple(bad[0][:-1])] if bad.size else None,
+                           want_bits.view(np.float32)[tuple(bad[0][:-1])] if bad.size else None)
+
+
+def test_transmittance_lut_shader(vec):
+    W, H = (int(v) for v in vec["transmittance_extent"])
+    got = np.zeros((len(vec["transmittance_xy"]), 4), np.float32)
+    with ob.use_literal():
+        for i, ((x, y), raw) in enumerate(zip(vec["transmittance_xy"], vec["transmittance_atm"])):
+            atm = _block(abi.AtmospherePacked, raw)
+            ob.lib().oracle_transmittance_texel(C.byref(atm), W, H, int(x), int(y), ob.fptr(got[i]))
+    _same(got, vec["transmittance_texel"], "transmittance_LUT.comp")
+    assert len(got) >= 60
+
+
+def test_skyview_lut_shader(vec):
+    W, H = (int(v) for v in vec["skyview_extent"])
+    got = np.zeros((len(vec["skyview_xy"]), 4), np.float32)
+    with ob.use_literal():
+        for i, (x, y) in enumerate(vec["skyview_xy"]):
+            atm = _block(abi.AtmospherePacked, vec["skyview_atm"][i])
+            cam = _block(abi.CameraPacked, vec["skyview_cam"][i])
+            tlut = _tlut(vec, int(vec["skyview_tlut"][i]))
+            row = ob.skyview_lut(atm, cam, tlut, W, H, row_begin=int(y), row_end=int(y) + 1, threads=8)
+            got[i] = row[int(y), int(x)]
+    _same(got, vec["skyview_texel"], "skyview_LUT.comp")
+    assert len(got) >= 50
+
+
+def _frame(vec, k):
+    atm = _block(abi.AtmospherePacked, vec[f"atm_{k}"])
+    cam = _block(abi.CameraPacked, vec[f"cam_{k}"])
+    dirs, ndirs = _array(abi.DirectionalLightPacked, vec[f"dirs_{k}"])
+    spots, nspots = _array(abi.SpotLightPacked, vec[f"spots_{k}"])
+    depth = vec[f"depth_{k}"]
+    H, W = depth.shape
+    frame = ob.HostFrame(W, H)
+    for name, plane in frame.planes().items():
+        plane[...] = vec[f"gbuffer_{name}_{k}"]
+    frame.depth[...] = depth
+    nslots = ndirs + nspots
+    keep = [np.ascontiguousarray(vec[f"shadow_{k}_{s}"]) for s in range(nslots)]
+    images = (abi.Image * nslots)()
+    for s in range(nslots):
+        images[s] = ob.host_image(keep[s], abi.SZG_FORMAT_D32_SFLOAT)
+    sm = abi.ShadowMaps(nslots, 0, C.cast(images, C.POINTER(abi.Image)))
+    return frame, atm, cam, dirs, ndirs, spots, nspots, sm, (keep, images)
+
+
+@pytest.mark.parametrize("k", range(6))
+def test_lights_and_camera_shaders(vec, k):
+    assert int(vec["scenarios"]) == 6
+    frame, atm, cam, dirs, ndirs, spots, nspots, sm, keep = _frame(vec, k)
+    H, W = frame.depth.shape
+    rect = abi.Rect(0, 0, W, H)
+    with ob.use_literal():
+        ob.lights(frame, rect, None, sm, cam, dirs, ndirs, 1, spots, nspots, threads=8)
+        xy = vec[f"lights_xy_{k}"]
+        _same(frame.debug[xy[:, 1], xy[:, 0]], vec[f"lights_value_{k}"], f"lights.comp scenario {k}")
+        assert np.array_equal(frame.color[xy[:, 1], xy[:, 0]], vec[f"lights_unorm_{k}"])
+        # geometry and background both occur
+        stored = vec[f"lights_stored_{k}"]
+        assert (stored.any() and not stored.all()) or k == 3  # (scenario 3 looks down from 2.5 km: sky and ground only)
+        assert np.array_equal(frame.color, vec[f"prior_{k}"])  # what camera.comp read back when the vectors were made
+        tlut = _tlut(vec, k)
+        slut = np.ascontiguousarray(vec[f"slut_{k}"])
+        ob.composite(frame, rect, None, sm, atm, cam, dirs, 0, tlut, slut, threads=8)
+        xy = vec[f"camera_xy_{k}"]
+        _same(frame.debug[xy[:, 1], xy[:, 0]], vec[f"camera_value_{k}"], f"camera.comp scenario {k}")
+        assert np.array_equal(frame.color[xy[:, 1], xy[:, 0]], vec[f"camera_unorm_{k}"])
+
+
+def test_the_default_oracle_differs_from_the_literal_one_only_in_the_last_places(vec):
+    """The contraction rule moves values by rounding errors, not by more: the parity oracle against the same vectors."""
+    k = 0
+    frame, atm, cam, dirs, ndirs, spots, nspots, sm, keep = _frame(vec, k)
+    H, W = frame.depth.shape
+    rect = abi.Rect(0, 0, W, H)
+    ob.lights(frame, rect, None, sm, cam, dirs, ndirs, 1, spots, nspots, threads=8)
+    xy = vec[f"lights_xy_{k}"]
+    want = vec[f"lights_value_{k}"].view(np.float32)
+    got = frame.debug[xy[:, 1], xy[:, 0]]
+    assert np.allclose(got, want, rtol=2e-5, atol=1e-7)
+    ob.composite(frame, rect, None, sm, atm, cam, dirs, 0, _tlut(vec, k), np.ascontiguousarray(vec[f"slut_{k}"]), threads=8)
+    xy = vec[f"camera_xy_{k}"]
+    want = vec[f"camera_value_{k}"].view(np.float32)
+    got = frame.debug[xy[:, 1], xy[:, 0]]
+    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
+    assert np.median(rel) < 1e-5 and rel.max() < 5e-2, (np.median(rel), rel.max())
+
+
+@pytest.mark.skipif(not gen.available(), reason="the reference's committed SPIR-V is only present in the build container")
+def test_committed_vectors_are_what_the_reference_binaries_produce(vec):
+    """Where the reference checkout exists, run the interpreter again and compare with the committed fixture."""
+    live = gen.generate(log=lambda *_: None)
+    assert sorted(live) == sorted(vec.files)
+    for name in vec.files:
+        assert np.array_equal(np.asarray(live[name]), vec[name]), name

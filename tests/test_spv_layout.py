@@ -9,7 +9,7 @@ pipeline creation (deferred.cpp:30-62, pipelines.cpp:609-624).
 What is asserted: include/szg/abi.h and include/szg/raster.h (measured with offsetof / sizeof by a C program compiled here,
 not by reading the header) and syzygy_amd/abi.py's ctypes mirrors have exactly those offsets and sizes.
 
-This pins LAYOUT. It pins no arithmetic: the shader math stays "parity unpinned" (DESIGN.md §2).
+This pins LAYOUT. The arithmetic of the same binaries is pinned by tests/test_spirv_pin.py.
 """
 import ctypes
 import json
