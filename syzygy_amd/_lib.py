@@ -17,7 +17,9 @@ class SzgError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "csrc", "libszg_hip.so")
+    # SZG_HIP_LIBRARY: tests/test_gpu_spirv_pin.py points a child process at csrc/libszg_hip_literal.so (the same kernels
+    # with the contraction rule switched off); nothing else sets it
+    return os.environ.get("SZG_HIP_LIBRARY") or os.path.join(_HERE, "csrc", "libszg_hip.so")
 
 
 def lib():

@@ -336,7 +336,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     // (numerators too: the one-correction division returns NaN for an infinite numerator where the quotient is inf — a
     // projection with entries near FLT_MAX — and is not verified for denormal ones)
     float const cz = (L.map != nullptr)
-                         ? __builtin_fmaf(R[10], m.position.z, __builtin_fmaf(R[9], m.position.y, R[8] * m.position.x)) + R[11]
+                         ? SZG_CFMA(R[10], m.position.z, SZG_CFMA(R[9], m.position.y, R[8] * m.position.x)) + R[11]
                          : 0.0f;
     bool const lean = waveAll(L.leanOK != 0u && positionModerate && inRange(fabsf(cw), lo, hi) && inRange(d2, lo, hi) &&
                             inRange(hd, 0x1p-40f, 8.0f) && leanNumerator(cx) && leanNumerator(cy) && leanNumerator(cz));
@@ -352,7 +352,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
         // exactly 0 iff sqrt(q) * 2 >= 1 iff q >= 0.25 (sqrt is monotonic, sqrt(0.25) = 0.5 exactly), so the
         // cull needs no square root. x / 0.5 == x * 2 exactly.
         float const ddx = sx - 0.5f, ddy = sy - 0.5f;
-        float const q = __builtin_fmaf(ddy, ddy, ddx * ddx); // dot(d, d) of distance()
+        float const q = SZG_CFMA(ddy, ddy, ddx * ddx); // dot(d, d) of distance()
         if (q >= 0.25f && cullable)
         {
             return splat(0.0f);
@@ -368,8 +368,8 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     {
         float const sz = divU(lean, cz, cw, ycw);
         // projectedNormal = shadowMatrix * vec4(normal, 0)
-        float const nx = __builtin_fmaf(R[3], 0.0f, __builtin_fmaf(R[2], m.normal.z, __builtin_fmaf(R[1], m.normal.y, R[0] * m.normal.x)));
-        float const ny = __builtin_fmaf(R[7], 0.0f, __builtin_fmaf(R[6], m.normal.z, __builtin_fmaf(R[5], m.normal.y, R[4] * m.normal.x)));
+        float const nx = SZG_CFMA(R[3], 0.0f, SZG_CFMA(R[2], m.normal.z, SZG_CFMA(R[1], m.normal.y, R[0] * m.normal.x)));
+        float const ny = SZG_CFMA(R[7], 0.0f, SZG_CFMA(R[6], m.normal.z, SZG_CFMA(R[5], m.normal.y, R[4] * m.normal.x)));
         float const fdx = sqrtf(1.0f - clampf(nx * nx, 0.0f, 1.0f));
         float const fdy = sqrtf(1.0f - clampf(ny * ny, 0.0f, 1.0f));
         shadow = sampleShadowMap(L.map, L.mapWidth, L.mapHeight, L.mapPitchFloats, mk3(sx, sy, sz), fdx, fdy);
@@ -427,9 +427,9 @@ SZG_DEV LightCull loadCull(const LightRec* __restrict__ L)
 SZG_DEV V3 projectRows(const LightCull& c, V3 p)
 {
     // (M * vec4(p, 1)).row as the oracle's operator* evaluates it: an fma chain over x, y, z, then + m3 * 1
-    float const cx = __builtin_fmaf(c.rx[2], p.z, __builtin_fmaf(c.rx[1], p.y, c.rx[0] * p.x)) + c.rx[3];
-    float const cy = __builtin_fmaf(c.ry[2], p.z, __builtin_fmaf(c.ry[1], p.y, c.ry[0] * p.x)) + c.ry[3];
-    float const cw = __builtin_fmaf(c.rw[2], p.z, __builtin_fmaf(c.rw[1], p.y, c.rw[0] * p.x)) + c.rw[3];
+    float const cx = SZG_CFMA(c.rx[2], p.z, SZG_CFMA(c.rx[1], p.y, c.rx[0] * p.x)) + c.rx[3];
+    float const cy = SZG_CFMA(c.ry[2], p.z, SZG_CFMA(c.ry[1], p.y, c.ry[0] * p.x)) + c.ry[3];
+    float const cw = SZG_CFMA(c.rw[2], p.z, SZG_CFMA(c.rw[1], p.y, c.rw[0] * p.x)) + c.rw[3];
     return V3{cx, cy, cw};
 }
 SZG_DEV bool surelyOutsideCone(V3 clip)

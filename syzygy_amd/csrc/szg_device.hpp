@@ -46,12 +46,22 @@ SZG_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 SZG_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
 // Contraction rule (oracle/szg_oracle.cpp header): dot, matrix * vector, mix, bilinear fetches, the LUT coordinate maps and
 // the march's geometry / accumulation use fused multiply-adds, explicitly and at the same places as the oracle; the
-// compiler itself contracts nothing (-ffp-contract=off).
-SZG_DEV float dot(V3 a, V3 b) { return __builtin_fmaf(a.z, b.z, __builtin_fmaf(a.y, b.y, a.x * b.x)); }
-SZG_DEV float dot(V2 a, V2 b) { return __builtin_fmaf(a.y, b.y, a.x * b.x); }
-SZG_DEV V3 fma3(V3 a, float s, V3 c) { return V3{__builtin_fmaf(a.x, s, c.x), __builtin_fmaf(a.y, s, c.y), __builtin_fmaf(a.z, s, c.z)}; }
-SZG_DEV V3 fma3(V3 a, V3 b, V3 c) { return V3{__builtin_fmaf(a.x, b.x, c.x), __builtin_fmaf(a.y, b.y, c.y), __builtin_fmaf(a.z, b.z, c.z)}; }
-SZG_DEV V3 fnma(float t, V3 d, V3 c) { return V3{__builtin_fmaf(-t, d.x, c.x), __builtin_fmaf(-t, d.y, c.y), __builtin_fmaf(-t, d.z, c.z)}; }
+// compiler itself contracts nothing (-ffp-contract=off). The rule is ONE switch, as in the oracle (SZG_FMA there):
+// -DSZG_LITERAL builds libszg_hip_literal.so, the same kernels with two roundings at those places, i.e. kernels that
+// execute the shaders' SPIR-V literally; tests/test_gpu_spirv_pin.py compares that build, bit for bit and on the GPU, with
+// the vectors an interpreter recorded from the reference's committed .spv (tests/golden/spirv_vectors.npz). The fused
+// multiply-adds INSIDE the exact operators below (rcpN, divR, sqrtN, exp / log polynomials) are not part of the rule: they
+// are how those operators reach their correctly rounded results, and stay.
+#ifdef SZG_LITERAL
+#define SZG_CFMA(a, b, c) ((a) * (b) + (c))
+#else
+#define SZG_CFMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#endif
+SZG_DEV float dot(V3 a, V3 b) { return SZG_CFMA(a.z, b.z, SZG_CFMA(a.y, b.y, a.x * b.x)); }
+SZG_DEV float dot(V2 a, V2 b) { return SZG_CFMA(a.y, b.y, a.x * b.x); }
+SZG_DEV V3 fma3(V3 a, float s, V3 c) { return V3{SZG_CFMA(a.x, s, c.x), SZG_CFMA(a.y, s, c.y), SZG_CFMA(a.z, s, c.z)}; }
+SZG_DEV V3 fma3(V3 a, V3 b, V3 c) { return V3{SZG_CFMA(a.x, b.x, c.x), SZG_CFMA(a.y, b.y, c.y), SZG_CFMA(a.z, b.z, c.z)}; }
+SZG_DEV V3 fnma(float t, V3 d, V3 c) { return V3{SZG_CFMA(-t, d.x, c.x), SZG_CFMA(-t, d.y, c.y), SZG_CFMA(-t, d.z, c.z)}; }
 SZG_DEV float length(V3 a) { return sqrtf(dot(a, a)); }
 SZG_DEV V3 normalize(V3 v)
 {
@@ -67,8 +77,8 @@ SZG_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), h
 SZG_DEV V3 clamp01(V3 v) { return V3{clampf(v.x, 0.0f, 1.0f), clampf(v.y, 0.0f, 1.0f), clampf(v.z, 0.0f, 1.0f)}; }
 SZG_DEV V3 mix(V3 a, V3 b, V3 w)
 {
-    return V3{__builtin_fmaf(b.x, w.x, a.x * (1.0f - w.x)), __builtin_fmaf(b.y, w.y, a.y * (1.0f - w.y)),
-              __builtin_fmaf(b.z, w.z, a.z * (1.0f - w.z))};
+    return V3{SZG_CFMA(b.x, w.x, a.x * (1.0f - w.x)), SZG_CFMA(b.y, w.y, a.y * (1.0f - w.y)),
+              SZG_CFMA(b.z, w.z, a.z * (1.0f - w.z))};
 }
 SZG_DEV float smoothstep(float e0, float e1, float x)
 {
@@ -219,10 +229,10 @@ struct M4
 SZG_DEV V4 mul(const M4& a, float x, float y, float z, float w)
 {
     V4 r;
-    r.x = __builtin_fmaf(a.m[12], w, __builtin_fmaf(a.m[8], z, __builtin_fmaf(a.m[4], y, a.m[0] * x)));
-    r.y = __builtin_fmaf(a.m[13], w, __builtin_fmaf(a.m[9], z, __builtin_fmaf(a.m[5], y, a.m[1] * x)));
-    r.z = __builtin_fmaf(a.m[14], w, __builtin_fmaf(a.m[10], z, __builtin_fmaf(a.m[6], y, a.m[2] * x)));
-    r.w = __builtin_fmaf(a.m[15], w, __builtin_fmaf(a.m[11], z, __builtin_fmaf(a.m[7], y, a.m[3] * x)));
+    r.x = SZG_CFMA(a.m[12], w, SZG_CFMA(a.m[8], z, SZG_CFMA(a.m[4], y, a.m[0] * x)));
+    r.y = SZG_CFMA(a.m[13], w, SZG_CFMA(a.m[9], z, SZG_CFMA(a.m[5], y, a.m[1] * x)));
+    r.z = SZG_CFMA(a.m[14], w, SZG_CFMA(a.m[10], z, SZG_CFMA(a.m[6], y, a.m[2] * x)));
+    r.w = SZG_CFMA(a.m[15], w, SZG_CFMA(a.m[11], z, SZG_CFMA(a.m[7], y, a.m[3] * x)));
     return r;
 }
 SZG_DEV M4 mul(const M4& a, const M4& b)
@@ -704,8 +714,8 @@ SZG_DEV TLut make_tlut(const float4* texels, int w, int h, const FramePrep& f)
 
 SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float fW, float fH, float s, float t)
 {
-    float const u = __builtin_fmaf(s, fW, -0.5f);
-    float const v = __builtin_fmaf(t, fH, -0.5f);
+    float const u = SZG_CFMA(s, fW, -0.5f);
+    float const v = SZG_CFMA(t, fH, -0.5f);
     float const fu = floorf(u);
     float const fv = floorf(v);
     float const a = u - fu;
@@ -725,9 +735,9 @@ SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float f
     float const w01 = (1.0f - a) * b;
     float const w11 = a * b;
     V3 r;
-    r.x = __builtin_fmaf(w11, t11.x, __builtin_fmaf(w01, t01.x, __builtin_fmaf(w10, t10.x, w00 * t00.x)));
-    r.y = __builtin_fmaf(w11, t11.y, __builtin_fmaf(w01, t01.y, __builtin_fmaf(w10, t10.y, w00 * t00.y)));
-    r.z = __builtin_fmaf(w11, t11.z, __builtin_fmaf(w01, t01.z, __builtin_fmaf(w10, t10.z, w00 * t00.z)));
+    r.x = SZG_CFMA(w11, t11.x, SZG_CFMA(w01, t01.x, SZG_CFMA(w10, t10.x, w00 * t00.x)));
+    r.y = SZG_CFMA(w11, t11.y, SZG_CFMA(w01, t01.y, SZG_CFMA(w10, t10.y, w00 * t00.y)));
+    r.z = SZG_CFMA(w11, t11.z, SZG_CFMA(w01, t01.z, SZG_CFMA(w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -759,8 +769,8 @@ template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const 
     p.denom = d_max - p.d_min;
     p.rcpDenom = LEAN ? rcpN(p.denom) : 0.0f;
     float const x_radius = divRX<LEAN>(rho, a.H, a.rcpH);
-    float const t = __builtin_fmaf(x_radius, L.v_scale, L.v_bias);
-    float const v = __builtin_fmaf(t, L.fheight, -0.5f);
+    float const t = SZG_CFMA(x_radius, L.v_scale, L.v_bias);
+    float const v = SZG_CFMA(t, L.fheight, -0.5f);
     float const fv = floorf(v);
     p.b = v - fv;
     p.omb = 1.0f - p.b;
@@ -782,11 +792,11 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
     // where a march segment has length 0 (geometry nearer than 32 ulps of the planet radius, ~15 m: normalize(0) = NaN,
     // common.glinl:114-136), and max(NaN, 0) = 0 is what the reference then samples with (found by the 6 000-seed sweep of
     // round 2: a version without this clamp let the NaN through to the texel weights in 8 of 6 000 random frames).
-    float const disc = __builtin_fmaf(p.r2, __builtin_fmaf(mu, mu, -1.0f), a.Ra2);
-    float const d = fmaxf(__builtin_fmaf(-p.r, mu, (LEAN && INNER) ? sqrtP(disc) : safeSqrtX<LEAN>(disc)), 0.0f);
+    float const disc = SZG_CFMA(p.r2, SZG_CFMA(mu, mu, -1.0f), a.Ra2);
+    float const d = fmaxf(SZG_CFMA(-p.r, mu, (LEAN && INNER) ? sqrtP(disc) : safeSqrtX<LEAN>(disc)), 0.0f);
     float const x_mu = divRX<LEAN>(d - p.d_min, p.denom, p.rcpDenom);
-    float const s = __builtin_fmaf(x_mu, L.u_scale, L.u_bias);
-    float const u = __builtin_fmaf(s, L.fwidth, -0.5f);
+    float const s = SZG_CFMA(x_mu, L.u_scale, L.u_bias);
+    float const u = SZG_CFMA(s, L.fwidth, -0.5f);
     float const fu = floorf(u);
     float const al = u - fu;
     float const wm1 = L.fwidth - 1.0f;
@@ -827,9 +837,9 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
     float const w01 = oma * p.b;
     float const w11 = al * p.b;
     V3 r;
-    r.x = __builtin_fmaf(w11, t11.x, __builtin_fmaf(w01, t01.x, __builtin_fmaf(w10, t10.x, w00 * t00.x)));
-    r.y = __builtin_fmaf(w11, t11.y, __builtin_fmaf(w01, t01.y, __builtin_fmaf(w10, t10.y, w00 * t00.y)));
-    r.z = __builtin_fmaf(w11, t11.z, __builtin_fmaf(w01, t01.z, __builtin_fmaf(w10, t10.z, w00 * t00.z)));
+    r.x = SZG_CFMA(w11, t11.x, SZG_CFMA(w01, t01.x, SZG_CFMA(w10, t10.x, w00 * t00.x)));
+    r.y = SZG_CFMA(w11, t11.y, SZG_CFMA(w01, t01.y, SZG_CFMA(w10, t10.y, w00 * t00.y)));
+    r.z = SZG_CFMA(w11, t11.z, SZG_CFMA(w01, t01.z, SZG_CFMA(w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -965,11 +975,11 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
 
         // stepRadiusMu(originStep, t), common.glinl:329-331
         // (on a lean path this is a squared radius above the lean floor: neither the clamp to 0 nor sqrtN's guard is needed)
-        float const s_q = __builtin_fmaf(m.two_r_mu, t, t * t) + m.r2;
+        float const s_q = SZG_CFMA(m.two_r_mu, t, t * t) + m.r2;
         float const s_radius = LEAN ? sqrtP(s_q) : safeSqrt(s_q);
         float const yS = LEAN ? rcpN(s_radius) : 0.0f;
         float const s_mu = divRX<LEAN>(m.r_mu + t, s_radius, yS);
-        float const s_musun = divRX<LEAN>(__builtin_fmaf(t, m.mu_sunAndStep, m.r_musun), s_radius, yS);
+        float const s_musun = divRX<LEAN>(SZG_CFMA(t, m.mu_sunAndStep, m.r_musun), s_radius, yS);
         RadiusPart const pStep = radiusPart<LEAN>(L, a, s_radius);
 
         float const altitude = lenBegin - a.planetRadius;
@@ -1103,7 +1113,7 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     // leanRay: every radius met along the path stays >= 0.9 Rp and of moderate magnitude, the path length is
     // moderate, and the smoothstep span 2 * sin_hz * sin(sunRadius) is a normal number. The closest approach of
     // the segment [0, L] to the planet centre is at t* = -r*mu when that lies inside the segment.
-    float const L2 = __builtin_fmaf(m.two_r_mu, sampleDistance, sampleDistance * sampleDistance) + m.r2; // stepRadiusMu's form
+    float const L2 = SZG_CFMA(m.two_r_mu, sampleDistance, sampleDistance * sampleDistance) + m.r2; // stepRadiusMu's form
     float const tStar = -m.r_mu;
     float const rmin2 = (tStar > 0.0f && tStar < sampleDistance) ? m.r2 * (1.0f - mu * mu) : fminf(m.r2, L2);
     // ... and the two cosines are cosines: a sun (or view) vector of length 0 or inf makes mu_sun (mu) infinite or NaN, and
