@@ -1899,12 +1899,16 @@ void oracle_oetf(const szg_image* image, uint32_t width, uint32_t height, uint32
                 {
                     bool const cutoff = linear <= 0.0031308f;
                     float const lower = 12.92f * linear;
-                    float const higher = GL_POW(linear, 1.0f / 2.4f) * 1.055f - 0.055f;
+                    float const higher = GL_POW(linear, (float)(1.0 / 2.4)) * 1.055f - 0.055f;
                     nonlinear = cutoff ? lower : higher; // mix(higher, lower, bvec cutoff)
                 }
                 else
                 {
-                    nonlinear = GL_POW(linear, 1.0f / 2.2f);
+                    // oetf_pure_gamma.comp:9 writes vec3(1 / 2.2): glslang folds the constant expression in double precision
+                    // and narrows the quotient, 0x3EE8BA2F in the committed SPIR-V - one ulp above the fp32 quotient
+                    // 1.0f / 2.2f (found by tests/test_spirv_pin.py: 174 of 196 608 code values differed). 1 / 2.4 of the sRGB
+                    // curve narrows to the same float either way.
+                    nonlinear = GL_POW(linear, (float)(1.0 / 2.2));
                 }
                 p[c] = unorm16_store(nonlinear);
             }

@@ -649,10 +649,11 @@ SZG_DEV float oetf(float linear, unsigned function)
     if (function == SZG_OETF_SRGB)
     {
         float const lower = 12.92f * linear;
-        float const higher = szg_powf(linear, 1.0f / 2.4f) * 1.055f - 0.055f;
+        float const higher = szg_powf(linear, (float)(1.0 / 2.4)) * 1.055f - 0.055f;
         return (linear <= 0.0031308f) ? lower : higher; // mix(higher, lower, cutoff)
     }
-    return szg_powf(linear, 1.0f / 2.2f);
+    // (float)(1.0 / 2.2), not 1.0f / 2.2f: the constant of the reference's SPIR-V, folded in double (oracle_oetf)
+    return szg_powf(linear, (float)(1.0 / 2.2));
 }
 SZG_DEV unsigned oetf_pair(unsigned packed, unsigned function, bool hiIsAlpha)
 {

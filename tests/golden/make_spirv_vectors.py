@@ -37,6 +37,8 @@ SHADERS = {
     "skyview": "shaders/atmosphere/skyview_LUT.comp.spv",
     "lights": "shaders/deferred/lights.comp.spv",
     "camera": "shaders/atmosphere/camera.comp.spv",
+    "oetf_srgb": "shaders/transfer/oetf_srgb.comp.spv",
+    "oetf_pure_gamma": "shaders/transfer/oetf_pure_gamma.comp.spv",
 }
 F32 = np.float32
 
@@ -389,6 +391,23 @@ def generate(log=print):
             out[f"camera_value_{k}"] = _bits(cam_f)
             out[f"camera_unorm_{k}"] = np.array(cam_q, np.uint16)
             log(f"camera scenario {k}: {len(pixels)} pixels, {time.time() - t_start:.0f} s")
+    # ------------------------------------------------------------------ oetf_srgb.comp / oetf_pure_gamma.comp --------------
+    # in place on the rgba16 scene colour: EVERY 16-bit code value in the red channel (green and blue walk the codes in other
+    # orders, alpha must pass through), one invocation per pixel of a 256 x 256 image
+    codes = np.arange(65536, dtype=np.uint32)
+    colour = np.stack([codes, 65535 - codes, (codes * 7919 + 13) % 65536, (codes * 31) % 65536], axis=1).astype(np.uint16).reshape(256, 256, 4)
+    out["oetf_input"] = colour
+    for name in ("oetf_srgb", "oetf_pure_gamma"):
+        m = mods[name]
+        image = Unorm16(colour)
+        it = si.Interpreter(m, si.Memory(), builtins, b"", {bindings(m)["image"]: image})
+        for y in range(256):
+            for x in range(256):
+                it.run((x, y, 0))
+        it.run((256, 0, 0))  # outside the image: no store
+        assert (256, 0) not in image.written
+        out[name] = np.array([image.written[(x, y)] for y in range(256) for x in range(256)], np.uint16).reshape(256, 256, 4)
+        log(f"{name}: 65536 pixels, {time.time() - t_start:.0f} s")
     out["scenarios"] = np.array(len(scenarios))
     out["lut_extents"] = np.array([TW, TH, SW, SH])
     return out

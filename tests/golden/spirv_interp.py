@@ -20,7 +20,7 @@ What "literally" means
   * PhysicalStorageBuffer pointers are integer addresses into `Memory`, decoded with the module's own Offset / ArrayStride /
     MatrixStride decorations.
 
-Supported: exactly the instruction set of the four hot-path shaders (82 opcodes, 16 extended instructions); anything else
+Supported: exactly the instruction set of the four hot-path shaders and the two OETF shaders (83 opcodes, 16 extended instructions); anything else
 raises NotImplementedError naming the opcode.
 """
 import struct
@@ -477,6 +477,8 @@ class Interpreter:
                     V[a[1]] = self._map(lambda x, y: bool(x == y), val(a[2]), val(a[3]))
                 elif op == 184:
                     V[a[1]] = self._map(lambda x, y: bool(x < y), val(a[2]), val(a[3]))
+                elif op == 188:
+                    V[a[1]] = self._map(lambda x, y: bool(x <= y), val(a[2]), val(a[3]))
                 elif op == 186:
                     V[a[1]] = self._map(lambda x, y: bool(x > y), val(a[2]), val(a[3]))
                 elif op == 190:

@@ -135,6 +135,17 @@ def test_lights_and_camera_shaders(vec, k):
         assert np.array_equal(frame.color[xy[:, 1], xy[:, 0]], vec[f"camera_unorm_{k}"])
 
 
+@pytest.mark.parametrize("name,function", [("oetf_pure_gamma", abi.SZG_OETF_PURE_GAMMA), ("oetf_srgb", abi.SZG_OETF_SRGB)])
+def test_oetf_shaders_every_code_value(vec, name, function):
+    """transfer/oetf_*.comp.spv on every 16-bit code value (red channel; the other channels walk the codes in other orders,
+    alpha passes through): the oracle's in-place OETF gives the same UNORM16 codes. (No product of the contraction rule
+    occurs in these shaders: the default build is the literal one.)"""
+    colour = np.ascontiguousarray(vec["oetf_input"]).copy()
+    got = ob.oetf(colour, function)
+    assert np.array_equal(got, vec[name])
+    assert np.array_equal(got[..., 3], vec["oetf_input"][..., 3])
+
+
 def test_the_default_oracle_differs_from_the_literal_one_only_in_the_last_places(vec):
     """The contraction rule moves values by rounding errors, not by more: the parity oracle against the same vectors."""
     k = 0
