@@ -474,6 +474,57 @@ void oracle_gbuffer_raster(const szg_scene_texture* scene, szg_rect drawRect, co
     });
 }
 
+// The two programmable stages alone, for tests/test_spirv_pin.py (the same expressions assembleScene and the shading loop
+// above evaluate). out: clip xyzw, world xyz, normal xyz, uv xy = 12 floats (depth pass: clip only).
+void oracle_vertex_stage(const szg_vertex_packed* vertex, const szg_mat4* model, const szg_mat4* modelInverseTranspose,
+                         const szg_mat4* projection, const szg_mat4* view, int shadow, float out[12])
+{
+    vec4 const local{vertex->position[0], vertex->position[1], vertex->position[2], 1.0f};
+    for (int i = 0; i < 12; i++)
+    {
+        out[i] = 0.0f;
+    }
+    vec4 clip;
+    if (shadow != 0)
+    {
+        clip = (load(*projection) * load(*model)) * local; // depthpass.vert:37
+    }
+    else
+    {
+        mat4 const projView = load(*projection) * load(*view);
+        vec4 const position = load(*model) * local;
+        clip = projView * position;
+        vec4 const n = load(*modelInverseTranspose) * vec4{vertex->normal[0], vertex->normal[1], vertex->normal[2], 0.0f};
+        vec3 const normal = normalize(vec3{n.x, n.y, n.z});
+        out[4] = position.x;
+        out[5] = position.y;
+        out[6] = position.z;
+        out[7] = normal.x;
+        out[8] = normal.y;
+        out[9] = normal.z;
+        out[10] = vertex->uv_x;
+        out[11] = vertex->uv_y;
+    }
+    out[0] = clip.x;
+    out[1] = clip.y;
+    out[2] = clip.z;
+    out[3] = clip.w;
+}
+// offscreen.frag on one fragment: interpolated inputs and the screen-space differences the fixed function hands to dFdx /
+// dFdy. out: worldPosition, normal, diffuse, specular, ORM (vec4 each, before the attachment's format conversion).
+void oracle_fragment_stage(const szg_material* material, const float world[3], const float normal[3], const float uv[2],
+                           const float dWorldDx[3], const float dWorldDy[3], const float dUvDx[2], const float dUvDy[2], float out[20])
+{
+    vec2 const st{uv[0], uv[1]};
+    vec3 const N = perturbNormal(*material, vec3{normal[0], normal[1], normal[2]}, vec3{dWorldDx[0], dWorldDx[1], dWorldDx[2]},
+                                 vec3{dWorldDy[0], dWorldDy[1], dWorldDy[2]}, vec2{dUvDx[0], dUvDx[1]}, vec2{dUvDy[0], dUvDy[1]}, st);
+    vec3 const color = sampleTexture(material->color, st);
+    vec3 const orm = sampleTexture(material->orm, st);
+    float const v[20] = {world[0], world[1], world[2], 1.0f, N.x, N.y, N.z, 0.0f, color.x, color.y, color.z, 1.0f,
+                         color.x, color.y, color.z, 1.0f, orm.x, orm.y, orm.z, 1.0f};
+    std::memcpy(out, v, sizeof v);
+}
+
 // One shadow map (pipelines.cpp:674-806): depth only, front faces culled, GREATER_OR_EQUAL against a 0 clear.
 void oracle_shadow_raster(const szg_image* map, const szg_mat4* projView, float depthBiasConstant, float depthBiasSlope,
                           const szg_mesh_instanced* meshes, uint32_t meshCount, int threads)

@@ -39,6 +39,9 @@ SHADERS = {
     "camera": "shaders/atmosphere/camera.comp.spv",
     "oetf_srgb": "shaders/transfer/oetf_srgb.comp.spv",
     "oetf_pure_gamma": "shaders/transfer/oetf_pure_gamma.comp.spv",
+    "offscreen_vert": "shaders/deferred/offscreen.vert.spv",
+    "offscreen_frag": "shaders/deferred/offscreen.frag.spv",
+    "depthpass_vert": "shaders/offscreenpass/depthpass.vert.spv",
 }
 F32 = np.float32
 
@@ -199,6 +202,72 @@ def _images():
     return Store, Unorm16, Nearest, Border, Linear
 
 
+def _texture_class(builtins):
+    from tests.golden import spirv_interp as si
+
+    class Texture(si.Image):
+        """RGBA8 material map: LINEAR, REPEAT, one level, sRGB-encoded texels decoded before filtering (include/szg/raster.h
+        "textures"; material.cpp samplers): binary32 weights, sum ((w00 t00 + w10 t10) + w01 t01) + w11 t11."""
+
+        def __init__(self, array, srgb):
+            self.a, self.srgb = array, srgb
+
+        def size(self):
+            return (self.a.shape[1], self.a.shape[0])
+
+        def _decode(self, byte):
+            c = F32(byte) / F32(255.0)
+            if not self.srgb:
+                return c
+            if c <= F32(0.04045):
+                return c / F32(12.92)
+            return builtins.pow((c + F32(0.055)) / F32(1.055), F32(2.4))
+
+        @staticmethod
+        def _wrap(f, n):
+            fn = F32(n)
+            m = f - fn * np.floor(f / fn)
+            i = int(m)
+            return 0 if (i >= n or i < 0) else i
+
+        def sample(self, sampler, s, t):
+            h, w = self.a.shape[:2]
+            one, half = F32(1), F32(0.5)
+            u = F32(s) * F32(w) - half
+            v = F32(t) * F32(h) - half
+            fu, fv = np.floor(u), np.floor(v)
+            a, b = u - fu, v - fv
+            i0, j0 = self._wrap(fu, w), self._wrap(fv, h)
+            i1 = 0 if i0 + 1 == w else i0 + 1
+            j1 = 0 if j0 + 1 == h else j0 + 1
+            w00, w10, w01, w11 = (one - a) * (one - b), a * (one - b), (one - a) * b, a * b
+            out = []
+            for c in range(3):
+                t00, t10, t01, t11 = (self._decode(self.a[j0, i0, c]), self._decode(self.a[j0, i1, c]),
+                                      self._decode(self.a[j1, i0, c]), self._decode(self.a[j1, i1, c]))
+                out.append(((w00 * t00 + w10 * t10) + w01 * t01) + w11 * t11)
+            return out + [F32(1)]
+
+    return Texture
+
+
+def pack_block(m, struct_type, values):
+    """Bytes of an explicitly laid out block (push constants) from {member name: int}, using the module's own offsets."""
+    from tests.golden import spirv_interp as si
+
+    t = m.types[struct_type]
+    raw = bytearray(128)
+    end = 0
+    for i, mt in enumerate(t.members):
+        name = m.member_names[(struct_type, i)]
+        off = m.member_decor[(struct_type, i)][si.DEC_OFFSET][0]
+        kind = m.types[mt].kind
+        size = 8 if kind == "pointer" or (kind == "int" and m.types[mt].width == 64) else 4
+        raw[off: off + size] = int(values[name]).to_bytes(size, "little")
+        end = max(end, off + size)
+    return bytes(raw[:end])
+
+
 def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
@@ -212,7 +281,7 @@ def generate(log=print):
     Store, Unorm16, Nearest, Border, Linear = _images()
     mods = {k: si.Module(os.path.join(REFERENCE, p)) for k, p in SHADERS.items()}
     for k, m in mods.items():
-        assert m.no_contraction == 0 and m.local_size == (16, 16, 1), k
+        assert m.no_contraction == 0 and (m.local_size == (16, 16, 1) or k.endswith(("_vert", "_frag"))), k
     builtins = Builtins()
     rng = np.random.default_rng(0x5A2C)
     out = {}
@@ -408,6 +477,82 @@ def generate(log=print):
         assert (256, 0) not in image.written
         out[name] = np.array([image.written[(x, y)] for y in range(256) for x in range(256)], np.uint16).reshape(256, 256, 4)
         log(f"{name}: 65536 pixels, {time.time() - t_start:.0f} s")
+    # ------------------------------------------------------------------ offscreen.vert / depthpass.vert / offscreen.frag -----
+    Texture = _texture_class(builtins)
+    nv, ni = 24, 3
+    vertices = (abi.VertexPacked * nv)()
+    for v in vertices:
+        v.position[:] = [float(F32(x)) for x in rng.uniform(-3, 3, 3)]
+        n = rng.normal(size=3)
+        v.normal[:] = [float(F32(x)) for x in n / np.linalg.norm(n) * rng.uniform(0.5, 2.0)]  # not unit: the shader normalises
+        v.uv_x, v.uv_y = float(F32(rng.uniform(-1, 2))), float(F32(rng.uniform(-1, 2)))
+        v.color[:] = [1.0, 1.0, 1.0, 1.0]
+    models = (abi.Mat4 * ni)()
+    mits = (abi.Mat4 * ni)()
+    for i in range(ni):
+        a = np.eye(4)
+        a[:3, :3] = rng.normal(size=(3, 3)) + 2.0 * np.eye(3)
+        a[:3, 3] = rng.uniform(-5, 5, 3)
+        models[i].m[:] = [float(F32(x)) for x in a.T.ravel()]  # column-major
+        mits[i].m[:] = [float(F32(x)) for x in np.linalg.inv(a).T.T.ravel()]
+    cam = scenarios[0].cam
+    light = abi.Mat4()
+    light.m[:] = [float(F32(x)) for x in (rng.normal(size=(4, 4)) * 0.1 + np.eye(4)).T.ravel()]
+    mem = si.Memory()
+    a_vert, a_model, a_mit = mem.alloc(bytes(vertices)), mem.alloc(bytes(models)), mem.alloc(bytes(mits))
+    a_cam = mem.alloc(b"\xff" * C.sizeof(abi.CameraPacked) + bytes(cam))  # camera 1 of its buffer
+    a_light = mem.alloc(bytes(light))
+    mv, md, mf = mods["offscreen_vert"], mods["depthpass_vert"], mods["offscreen_frag"]
+
+    def block_type(m):
+        (gid,) = [g for g, (pt, sc) in m.globals.items() if sc == si.SC_PUSH_CONSTANT]
+        return m.types[m.globals[gid][0]].pointee
+
+    itv = si.Interpreter(mv, mem, builtins, pack_block(mv, block_type(mv), dict(vertexBuffer=a_vert, modelBuffer=a_model,
+                         modelInverseTransposeBuffer=a_mit, cameraBuffer=a_cam, cameraIndex=1)), {})
+    itd = si.Interpreter(md, mem, builtins, pack_block(md, block_type(md), dict(vertexBuffer=a_vert, modelBuffer=a_model,
+                         projViewBuffer=a_light, projViewIndex=0)), {})
+    vs, ds = [], []
+    for inst in range(ni):
+        for vi in range(nv):
+            io = {si.BUILTIN_VERTEX_INDEX: vi, si.BUILTIN_INSTANCE_INDEX: inst}
+            itv.run(inputs=io)
+            o = itv.outputs
+            vs.append(list(o["gl_PerVertex"][0][0]) + list(o["outWorldPosition"][0]) + list(o["outNormal"][0]) + list(o["outTexCoord"][0]))
+            itd.run(inputs=io)
+            ds.append(list(itd.outputs["gl_PerVertex"][0][0]))
+    out.update(raster_vertices=np.frombuffer(bytes(vertices), np.uint8), raster_models=np.frombuffer(bytes(models), np.uint8),
+               raster_mits=np.frombuffer(bytes(mits), np.uint8), raster_camera=np.frombuffer(bytes(cam), np.uint8),
+               raster_light=np.frombuffer(bytes(light), np.uint8), offscreen_vert=_bits(vs), depthpass_vert=_bits(ds))
+    log(f"vertex stages: {len(vs)} + {len(ds)} invocations, {time.time() - t_start:.0f} s")
+
+    tex = {"color": rng.integers(0, 256, (5, 7, 4), dtype=np.uint8), "normal": rng.integers(0, 256, (4, 4, 4), dtype=np.uint8),
+           "ORM": rng.integers(0, 256, (3, 6, 4), dtype=np.uint8)}
+    bf = bindings(mf)
+    itf = si.Interpreter(mf, si.Memory(), builtins, b"", {bf["color"]: Texture(tex["color"], True), bf["normal"]: Texture(tex["normal"], False),
+                                                          bf["ORM"]: Texture(tex["ORM"], False)})
+    frag_in, frag_out = [], []
+    for _ in range(160):
+        world = [F32(x) for x in rng.uniform(-20, 20, 3)]
+        n = rng.normal(size=3)
+        normal = [F32(x) for x in n / np.linalg.norm(n)]
+        uv = [F32(x) for x in rng.uniform(-2, 3, 2)]
+        dwx = [F32(x) for x in rng.normal(size=3) * 0.05]
+        dwy = [F32(x) for x in rng.normal(size=3) * 0.05]
+        dux = [F32(x) for x in rng.normal(size=2) * 0.01]
+        duy = [F32(x) for x in rng.normal(size=2) * 0.01]
+        # cotangentFrame differentiates p = -inWorldPosition (offscreen.frag:54, :65): the fixed function hands it the negated
+        # differences
+        itf.run(inputs={"inWorldPosition": world, "inNormal": normal, "inTexCoord": uv},
+                derivatives=[[-c for c in dwx], [-c for c in dwy], dux, duy])
+        assert not itf.derivatives
+        o = itf.outputs
+        frag_in.append(world + normal + uv + dwx + dwy + dux + duy)
+        frag_out.append(list(o["outWorldPosition"][0]) + list(o["outNormal"][0]) + list(o["outDiffuseColor"][0]) +
+                        list(o["outSpecularColor"][0]) + list(o["outOcclusionRoughnessMetallic"][0]))
+    out.update(frag_in=_bits(frag_in), offscreen_frag=_bits(frag_out), frag_tex_color=tex["color"], frag_tex_normal=tex["normal"],
+               frag_tex_orm=tex["ORM"])
+    log(f"fragment stage: {len(frag_out)} invocations, {time.time() - t_start:.0f} s")
     out["scenarios"] = np.array(len(scenarios))
     out["lut_extents"] = np.array([TW, TH, SW, SH])
     return out

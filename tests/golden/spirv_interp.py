@@ -20,7 +20,7 @@ What "literally" means
   * PhysicalStorageBuffer pointers are integer addresses into `Memory`, decoded with the module's own Offset / ArrayStride /
     MatrixStride decorations.
 
-Supported: exactly the instruction set of the four hot-path shaders and the two OETF shaders (83 opcodes, 16 extended instructions); anything else
+Supported: exactly the instruction set of the four hot-path shaders and the two OETF shaders and the three raster-pass shaders (86 opcodes, 18 extended instructions); anything else
 raises NotImplementedError naming the opcode.
 """
 import struct
@@ -37,11 +37,11 @@ def clone(v):
 _ERR = dict(over="ignore", invalid="ignore", divide="ignore", under="ignore")
 
 # storage classes
-SC_UNIFORM_CONSTANT, SC_INPUT, SC_PRIVATE, SC_FUNCTION, SC_PUSH_CONSTANT, SC_PSB = 0, 1, 6, 7, 9, 5349
+SC_UNIFORM_CONSTANT, SC_INPUT, SC_OUTPUT, SC_PRIVATE, SC_FUNCTION, SC_PUSH_CONSTANT, SC_PSB = 0, 1, 3, 6, 7, 9, 5349
 # decorations
 DEC_BUILTIN, DEC_BINDING, DEC_SET, DEC_OFFSET, DEC_ARRAY_STRIDE, DEC_MATRIX_STRIDE, DEC_COL_MAJOR, DEC_ROW_MAJOR = 11, 33, 34, 35, 6, 7, 5, 4
 DEC_NO_CONTRACTION = 42
-BUILTIN_GLOBAL_INVOCATION_ID = 28
+BUILTIN_GLOBAL_INVOCATION_ID, BUILTIN_VERTEX_INDEX, BUILTIN_INSTANCE_INDEX = 28, 42, 43
 
 
 class Type:
@@ -322,15 +322,30 @@ class Interpreter:
             acc = acc + x * y
         return acc
 
-    def run(self, global_id):
+    def run(self, global_id=None, inputs=None, derivatives=None):
+        """One invocation. Compute: `global_id`. Vertex / fragment stages: `inputs` maps a variable NAME (or a BuiltIn
+        number) to its value; the Output variables are left in `self.outputs` by name (gl_PerVertex members as a list).
+        `derivatives`: the values OpDPdx / OpDPdy return, in execution order (fixed function, supplied by the caller)."""
         m = self.m
         self.globals = {}
+        self.outputs = {}
+        self.derivatives = list(derivatives or [])
+        inputs = inputs or {}
         for gid, (ptype, storage) in m.globals.items():
             pointee = m.types[ptype].pointee
             d = m.decor.get(gid, {})
             if storage == SC_INPUT:
-                assert d.get(DEC_BUILTIN, [None])[0] == BUILTIN_GLOBAL_INVOCATION_ID, "only gl_GlobalInvocationID is read"
-                self.globals[gid] = Ref([list(global_id)])
+                builtin = d.get(DEC_BUILTIN, [None])[0]
+                if builtin == BUILTIN_GLOBAL_INVOCATION_ID:
+                    self.globals[gid] = Ref([list(global_id)])
+                elif builtin is not None:
+                    self.globals[gid] = Ref([inputs[builtin]])
+                else:
+                    self.globals[gid] = Ref([clone(inputs[m.names[gid]])])
+            elif storage == SC_OUTPUT:
+                cell = [self._zero(pointee)]
+                self.globals[gid] = Ref(cell)
+                self.outputs[m.names.get(gid) or "gl_PerVertex"] = cell
             elif storage == SC_PUSH_CONSTANT:
                 self.globals[gid] = ("pc", self.pc_base, pointee)
             elif storage == SC_UNIFORM_CONSTANT:
@@ -488,10 +503,10 @@ class Interpreter:
                 elif op == 100:  # Image
                     s = val(a[2])
                     V[a[1]] = s.image if isinstance(s, SampledImage) else s
-                elif op == 88:  # ImageSampleExplicitLod
+                elif op in (87, 88):  # ImageSampleImplicitLod (single-level images: the level is 0) / ImageSampleExplicitLod
                     s = val(a[2])
                     coord = val(a[3])
-                    assert a[4] == 2 and float(val(a[5])) == 0.0, "only Lod 0 occurs"
+                    assert op == 87 or (a[4] == 2 and float(val(a[5])) == 0.0), "only Lod 0 occurs"
                     img, smp = (s.image, s.sampler) if isinstance(s, SampledImage) else (s, None)
                     V[a[1]] = [F32(x) for x in img.sample(smp, coord[0], coord[1])]
                 elif op == 98:  # ImageRead
@@ -504,6 +519,8 @@ class Interpreter:
                     s = val(a[2])
                     img = s.image if isinstance(s, SampledImage) else s
                     V[a[1]] = list(img.size())
+                elif op in (207, 208):  # DPdx / DPdy: fixed function, the caller's values in execution order
+                    V[a[1]] = clone(self.derivatives.pop(0))
                 elif op in (246, 247):  # LoopMerge / SelectionMerge
                     pass
                 elif op == 249:
@@ -600,6 +617,11 @@ class Interpreter:
             return mp(b.exp, x[0])
         if inst == 31:
             return mp(lambda v: F32(np.sqrt(v)), x[0])
+        if inst == 32:  # InverseSqrt = 1 / sqrt(x), two correctly rounded operations
+            return mp(lambda v: F32(1) / F32(np.sqrt(v)), x[0])
+        if inst == 68:  # Cross
+            p, q = x[0], x[1]
+            return [p[1] * q[2] - p[2] * q[1], p[2] * q[0] - p[0] * q[2], p[0] * q[1] - p[1] * q[0]]
         if inst == 37:
             return mp(b.fmin, x[0], x[1])
         if inst == 40:

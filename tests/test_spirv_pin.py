@@ -146,6 +146,52 @@ def test_oetf_shaders_every_code_value(vec, name, function):
     assert np.array_equal(got[..., 3], vec["oetf_input"][..., 3])
 
 
+def test_raster_pass_vertex_shaders(vec):
+    """offscreen.vert and depthpass.vert (the programmable stage in front of the fixed-function rasteriser): clip position,
+    world position, normalised normal and texture coordinate of 24 vertices x 3 instances against the oracle's vertex stage."""
+    lib = ob.lib_literal()
+    FP = C.POINTER(C.c_float)
+    lib.oracle_vertex_stage.argtypes = [C.POINTER(abi.VertexPacked), C.POINTER(abi.Mat4), C.POINTER(abi.Mat4), C.POINTER(abi.Mat4),
+                                        C.POINTER(abi.Mat4), C.c_int, FP]
+    vertices, nv = _array(abi.VertexPacked, vec["raster_vertices"])
+    models, ni = _array(abi.Mat4, vec["raster_models"])
+    mits, _ = _array(abi.Mat4, vec["raster_mits"])
+    cam = _block(abi.CameraPacked, vec["raster_camera"])
+    light = _block(abi.Mat4, vec["raster_light"])
+    got_v = np.zeros((ni * nv, 12), np.float32)
+    got_d = np.zeros((ni * nv, 12), np.float32)
+    for inst in range(ni):
+        for vi in range(nv):
+            k = inst * nv + vi
+            lib.oracle_vertex_stage(C.byref(vertices[vi]), C.byref(models[inst]), C.byref(mits[inst]), C.byref(cam.projection),
+                                    C.byref(cam.view), 0, got_v[k].ctypes.data_as(FP))
+            lib.oracle_vertex_stage(C.byref(vertices[vi]), C.byref(models[inst]), None, C.byref(light), None, 1,
+                                    got_d[k].ctypes.data_as(FP))
+    _same(got_v, vec["offscreen_vert"], "offscreen.vert")
+    _same(got_d[:, :4], vec["depthpass_vert"], "depthpass.vert")
+    assert len(got_v) == 72
+
+
+def test_gbuffer_fragment_shader(vec):
+    """offscreen.frag on 160 fragments with random interpolants, screen-space differences and 8-bit material maps (sRGB
+    colour map, REPEAT addressing): all five G-buffer outputs against the oracle's fragment stage."""
+    lib = ob.lib_literal()
+    FP = C.POINTER(C.c_float)
+    lib.oracle_fragment_stage.argtypes = [C.POINTER(abi.Material)] + [FP] * 8
+    keep = {n: np.ascontiguousarray(vec[f"frag_tex_{n}"]) for n in ("color", "normal", "orm")}
+    mat = abi.Material()
+    for n, field in (("color", mat.color), ("normal", mat.normal), ("orm", mat.orm)):
+        a = keep[n]
+        field.data, field.height, field.width, field.pitch_bytes, field.srgb = a.ctypes.data, a.shape[0], a.shape[1], a.strides[0], int(n == "color")
+    fin = np.ascontiguousarray(vec["frag_in"]).view(np.float32)
+    got = np.zeros((len(fin), 20), np.float32)
+    for i, row in enumerate(fin):
+        parts = [np.ascontiguousarray(row[a:b]) for a, b in ((0, 3), (3, 6), (6, 8), (8, 11), (11, 14), (14, 16), (16, 18))]
+        lib.oracle_fragment_stage(C.byref(mat), *[p.ctypes.data_as(FP) for p in parts], got[i].ctypes.data_as(FP))
+    _same(got, vec["offscreen_frag"], "offscreen.frag")
+    assert len(got) == 160
+
+
 def test_the_default_oracle_differs_from_the_literal_one_only_in_the_last_places(vec):
     """The contraction rule moves values by rounding errors, not by more: the parity oracle against the same vectors."""
     k = 0
