@@ -505,6 +505,26 @@ def main():
                                       "frac_of_8TBps": 52 * W * H / (raster_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "in_value": False}
         raster_pipe.cleanup()
 
+    if extras and "SZG_HIP_LIBRARY" not in os.environ:
+        # The literal build of the same kernels (libszg_hip_literal.so: the contraction rule switched off, bit-identical to
+        # the reference's SPIR-V executed literally, tests/test_gpu_spirv_pin.py), timed by a child process on the same
+        # workload. NOT part of `value`: it says what the one switch costs and how far the two images are apart.
+        import subprocess
+
+        literal = os.path.join(ROOT, "syzygy_amd", "csrc", "libszg_hip_literal.so")
+        if os.path.exists(literal):
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", name, "--steps", str(args.steps), "--warmup",
+                                    str(args.warmup), "--no-cpu-baseline", "--no-extras"], env=dict(os.environ, SZG_HIP_LIBRARY=literal),
+                                   capture_output=True, text=True, timeout=300)
+                lit = json.loads(r.stdout.strip().split("\n")[-1])
+                out["literal_build"] = {"in_value": False, "library": "libszg_hip_literal.so", "ms_per_frame": lit["ms_per_step"],
+                                        "mpixels_per_s": lit["value"], "image_checksum": lit["image_checksum"],
+                                        "note": "same kernels with two roundings at the places where the product fuses a * b + c; "
+                                                "reproduces the reference's SPIR-V vectors bit for bit (tests/test_gpu_spirv_pin.py)"}
+            except Exception as e:  # the extra must never take the bench line down
+                log(f"literal_build extra failed: {e}")
+
     if rank == 0 and not args.no_cpu_baseline and args.gpus == 1:
         out["cpu_baseline"] = cpu_baseline(args, wl, atm, cam, sun, moon, spots, syn)
     if rank == 0:
