@@ -323,7 +323,10 @@ int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t
 /* The rows rank `rank` of `nranks` computes (an even split; the LUT height must divide), and the exchange that completes
  * the LUT on every rank: one in-place all-gather of the slices on `stream` (szg_rowtile_allgather on the pipeline's own
  * LUT memory). The sky-view LUT is the Amdahl term of the row-tiled frame (identical on every rank), hence this second,
- * optional collective of SURVEY 8e. */
+ * optional collective of SURVEY 8e. The LUT's status word ("every texel is a finite number", see
+ * szg_skyview_invalidate_luts) travels with it: each rank contributes the status of the rows it recorded with
+ * szg_skyview_record_skyview_lut_rows (or "unknown" when its last slice launch was not exactly its share), the words are
+ * all-gathered beside the slices (at most 64 ranks) and OR-ed, so no rank re-scans texels another rank wrote. */
 struct szg_rowtile_comm;
 int szg_skyview_lut_row_slice(const szg_skyview_t* p, uint32_t rank, uint32_t nranks, uint32_t* row_begin, uint32_t* row_end);
 int szg_skyview_allgather_lut_rows(szg_skyview_t* p, struct szg_rowtile_comm* comm, void* stream);

@@ -251,6 +251,29 @@ __global__ __launch_bounds__(256) void k_slut_check(float4* __restrict__ lut, un
     }
 }
 
+// The status dwords of the ranks' sky-view LUT slices, exchanged beside the slices (szg_skyview_allgather_lut_rows): each rank
+// stages the status of ITS rows (or 1 = "not known to be moderate" when no slice launch of this pipeline produced it), the
+// words are all-gathered, and the LUT's own status dword becomes their OR - instead of a 32 MiB re-scan of the gathered texels.
+__global__ void k_slut_status_stage(unsigned* __restrict__ all, unsigned rank, const unsigned* __restrict__ status, unsigned known)
+{
+    if (threadIdx.x == 0u)
+    {
+        all[rank] = known != 0u ? status[0] : 1u;
+    }
+}
+__global__ void k_slut_status_reduce(const unsigned* __restrict__ all, unsigned nranks, unsigned* __restrict__ status)
+{
+    if (threadIdx.x == 0u)
+    {
+        unsigned v = 0u;
+        for (unsigned r = 0; r < nranks; r++)
+        {
+            v |= all[r];
+        }
+        status[0] = v;
+    }
+}
+
 // Aerial-perspective froxel LUT (include/szg/abi.h "Aerial-perspective froxel LUT"): one froxel per lane, the
 // exact reference math per froxel (32768 marches; cost ~ 1/64 of the sky-view LUT).
 __global__ __launch_bounds__(256) void k_aerial_lut(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
@@ -503,6 +526,18 @@ hipError_t launch_slut_check(hipStream_t s, float* lut, unsigned W, unsigned H)
     return hipGetLastError();
 }
 
+hipError_t launch_slut_status_stage(hipStream_t s, unsigned* d_all, unsigned rank, const float* lut, unsigned W, unsigned H, bool known)
+{
+    hipLaunchKernelGGL(k_slut_status_stage, dim3(1), dim3(64), 0, s, d_all, rank,
+                       reinterpret_cast<const unsigned*>(lut + (size_t)W * H * 4u), known ? 1u : 0u);
+    return hipGetLastError();
+}
+hipError_t launch_slut_status_reduce(hipStream_t s, const unsigned* d_all, unsigned nranks, float* lut, unsigned W, unsigned H)
+{
+    hipLaunchKernelGGL(k_slut_status_reduce, dim3(1), dim3(64), 0, s, d_all, nranks, reinterpret_cast<unsigned*>(lut + (size_t)W * H * 4u));
+    return hipGetLastError();
+}
+
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
                           unsigned rowBegin, unsigned rowEnd, const unsigned* d_dirty, const void* d_prep)
@@ -515,10 +550,11 @@ hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
     {
         return hipSuccess;
     }
-    if (rowBegin == 0u && rowEnd == H && d_dirty == nullptr)
+    if (d_dirty == nullptr)
     {
-        // a whole LUT: its status dword starts clear and the kernel sets it (partial launches leave it to launch_slut_check;
-        // with LUT reuse k_lut_key clears it)
+        // the status dword starts clear and the kernel sets it: for a whole LUT that is its status, for a row slice the status
+        // of THAT slice, which szg_skyview_allgather_lut_rows exchanges with the other ranks' (any other consumer of a
+        // partly written LUT re-scans it, launch_slut_check); with LUT reuse k_lut_key clears it
         hipError_t const e = hipMemsetAsync(lut + (size_t)W * H * 4u, 0, 4, s);
         if (e != hipSuccess)
         {

@@ -297,6 +297,10 @@ struct szg_skyview
     // the same for the sky-view LUT's status dword (szg_launch.hpp "sky-view LUT block"): false after a partial (row-slice)
     // launch or after szg_skyview_skyview_lut() handed the texels out
     mutable bool slutStatusValid = false;
+    // the status dword behind the sky-view LUT currently describes exactly the rows of this pipeline's last slice launch
+    mutable bool sliceStatusKnown = false;
+    uint32_t sliceRowBegin = 0, sliceRowEnd = 0; // ... which were these rows
+    unsigned* d_slutStatusAll = nullptr; // szg::SLUT_STATUS_RANKS dwords: the ranks' slice status words (szg_skyview_allgather_lut_rows)
     // LUT reuse across frames (szg_launch.hpp "LUT reuse"; off by default = the reference's recompute-every-frame)
     bool lutReuse = false;
     unsigned* d_lutKey = nullptr;                      // LUT_KEY_DWORDS dwords of device state
@@ -467,6 +471,10 @@ int szg_skyview_create(szg_skyview_t** out, const szg_skyview_desc* desc, int de
     }
     if (e == hipSuccess)
     {
+        e = hipMalloc(reinterpret_cast<void**>(&p->d_slutStatusAll), szg::SLUT_STATUS_RANKS * sizeof(unsigned));
+    }
+    if (e == hipSuccess)
+    {
         e = hipMalloc(&p->d_framePrepDraw, szg::frame_prep_bytes());
     }
     if (e != hipSuccess)
@@ -506,6 +514,7 @@ int szg_skyview_invalidate_luts(szg_skyview_t* p, uint32_t which)
     if ((which & SZG_LUT_SKYVIEW) != 0u)
     {
         p->slutStatusValid = false;
+        p->sliceStatusKnown = false;
         p->forceSkyview = true;
     }
     return SZG_OK;
@@ -546,6 +555,10 @@ void szg_skyview_destroy(szg_skyview_t* p)
     {
         (void)hipFree(p->d_framePrep);
     }
+    if (p->d_slutStatusAll != nullptr)
+    {
+        (void)hipFree(p->d_slutStatusAll);
+    }
     if (p->d_framePrepDraw != nullptr)
     {
         (void)hipFree(p->d_framePrepDraw);
@@ -574,6 +587,7 @@ int szg_skyview_skyview_lut(const szg_skyview_t* p, szg_image* out)
     }
     *out = make_image(p->d_skyview, p->desc.skyview_width, p->desc.skyview_height, SZG_FORMAT_RGBA32_SFLOAT);
     p->slutStatusValid = false; // the caller may write the texels through this view (row slices gathered from other ranks)
+    p->sliceStatusKnown = false;
     p->forceSkyview = true;
     return SZG_OK;
 }
@@ -635,6 +649,9 @@ int szg_skyview_record_skyview_lut_rows(szg_skyview_t* p, void* stream, uint32_t
     p->haveSkyview = true;
     // a launch over all rows leaves the status dword behind the texels right; a slice does not know the other rows
     p->slutStatusValid = whole;
+    p->sliceStatusKnown = !whole && dirty == nullptr; // (launch_skyview cleared the dword, the slice's waves set it)
+    p->sliceRowBegin = row_begin;
+    p->sliceRowEnd = row_end;
     p->forceSkyview = !whole; // a slice leaves the other rows to someone else: no key describes the whole LUT
     return SZG_OK;
 }
@@ -668,12 +685,36 @@ int szg_skyview_allgather_lut_rows(szg_skyview_t* p, szg_rowtile_comm_t* comm, v
         return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_allgather_lut_rows: %u LUT rows do not divide over %d ranks",
                     p->desc.skyview_height, nranks);
     }
+    if (nranks > (int)szg::SLUT_STATUS_RANKS)
+    {
+        return fail(SZG_ERR_INVALID_ARGUMENT, "szg_skyview_allgather_lut_rows: more than %u ranks", szg::SLUT_STATUS_RANKS);
+    }
     DeviceGuard const guard(p->device);
+    hipStream_t const s = static_cast<hipStream_t>(stream);
     size_t const slice = (size_t)(p->desc.skyview_height / (uint32_t)nranks) * p->desc.skyview_width * 16u;
-    int const rc = szg_rowtile_allgather(comm, stream, p->d_skyview, slice);
-    // texels written by other ranks: the next consumer re-scans them (status dword) and no reuse key describes them
-    p->slutStatusValid = false;
-    p->forceSkyview = true;
+    // this rank's status word first (the dword behind the texels is overwritten by nobody: the slices end in front of it).
+    // It is known when the dword describes the whole LUT, or exactly the rows this rank contributes.
+    unsigned const rank = (unsigned)szg_rowtile_comm_rank(comm);
+    uint32_t const rowsPerRank = p->desc.skyview_height / (uint32_t)nranks;
+    bool const known = p->slutStatusValid ||
+                       (p->sliceStatusKnown && p->sliceRowBegin == rank * rowsPerRank && p->sliceRowEnd == (rank + 1u) * rowsPerRank);
+    SZG_HIP(szg::launch_slut_status_stage(s, p->d_slutStatusAll, rank, p->d_skyview, p->desc.skyview_width,
+                                          p->desc.skyview_height, known));
+    int rc = szg_rowtile_allgather(comm, stream, p->d_skyview, slice);
+    if (rc == SZG_OK)
+    {
+        // ... and the ranks' status words beside the slices: the LUT's status dword becomes their OR, so the composite needs
+        // no 32 MiB re-scan of texels other ranks wrote. Every rank makes this second, 4-byte exchange unconditionally.
+        rc = szg_rowtile_allgather(comm, stream, p->d_slutStatusAll, sizeof(unsigned));
+    }
+    if (rc == SZG_OK)
+    {
+        SZG_HIP(szg::launch_slut_status_reduce(s, p->d_slutStatusAll, (unsigned)nranks, p->d_skyview, p->desc.skyview_width,
+                                               p->desc.skyview_height));
+    }
+    p->slutStatusValid = (rc == SZG_OK);
+    p->sliceStatusKnown = false;
+    p->forceSkyview = true; // no reuse key describes texels other ranks wrote
     return rc;
 }
 

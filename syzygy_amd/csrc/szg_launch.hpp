@@ -66,6 +66,7 @@ hipError_t launch_transmittance(hipStream_t s, const szg_atmosphere_packed* d_at
 // verdict. LUT_KEY_DWORDS dwords of state, zeroed at creation; `force` = the host knows the texels are stale (first use,
 // texels handed out for writing, a row-slice launch, an explicit invalidate).
 constexpr unsigned LUT_KEY_DWORDS = 72u;
+constexpr unsigned SLUT_STATUS_RANKS = 64u; // most ranks szg_skyview_allgather_lut_rows exchanges slice status words of
 hipError_t launch_lut_key(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, unsigned* d_state, unsigned which, bool force, float* lutBlock, unsigned W, unsigned H);
 // Sky-view LUT block: W*H RGBA32F texels followed by ONE status dword (16 bytes reserved): 0 when every texel's rgb is a
@@ -75,6 +76,10 @@ hipError_t launch_lut_key(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
 // caller, launch_slut_check recomputes it from the texels.
 inline size_t slut_block_bytes(unsigned W, unsigned H) { return (size_t)W * H * 16u + 16u; }
 hipError_t launch_slut_check(hipStream_t s, float* lut, unsigned W, unsigned H);
+// The N-rank form of the same: the status of this rank's slice goes into d_all[rank] (1 when `known` is false), the caller
+// all-gathers d_all (4 bytes per rank), and the LUT's status dword becomes the OR of the nranks words.
+hipError_t launch_slut_status_stage(hipStream_t s, unsigned* d_all, unsigned rank, const float* lut, unsigned W, unsigned H, bool known);
+hipError_t launch_slut_status_reduce(hipStream_t s, const unsigned* d_all, unsigned nranks, float* lut, unsigned W, unsigned H);
 hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, const szg_camera_packed* d_cam,
                           unsigned camIndex, const float* tlut, unsigned tW, unsigned tH, float* lut, unsigned W, unsigned H,
                           unsigned rowBegin, unsigned rowEnd, const unsigned* d_dirty, const void* d_prep);

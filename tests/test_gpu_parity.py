@@ -1269,6 +1269,79 @@ def test_c_abi_collectives_on_rccl_single_rank(gpu):
     sky.destroy()
 
 
+def _slut_status_word(gpu, sky):
+    """The status dword behind the sky-view LUT's texels (szg_launch.hpp "sky-view LUT block")."""
+    im = sky.skyviewLUT()
+    word = gpu.abi.Image()
+    word.data = im.data + im.width * im.height * 16
+    word.width, word.height, word.pitch_bytes, word.format = 1, 1, 16, im.format
+    return int(gpu.pl._memcpy2d_from(word, 4, 1).cpu().numpy().view(np.uint32)[0])
+
+
+def test_slice_status_travels_with_the_lut_all_gather(gpu):
+    """Review of round 1, item 9: the sky-view LUT's status word ("every texel is a finite number", which lets the composite
+    leave samples unevaluated) used to be recomputed by a 32 MiB scan after every all-gather of the ranks' slices. Now each
+    rank contributes the status of ITS rows and the words are exchanged beside the slices (world of one here, RCCL through the
+    C-ABI): a clean slice gives a clean LUT and the plain frame; texels of unknown provenance (scribbled behind the pipeline's
+    back, then declared) count as "not known to be finite", and the frame is the oracle's frame for that NaN LUT."""
+    from syzygy_amd import rowtile
+
+    W, H = 96, 64
+    inp = util.Inputs(W, H, elevation_degrees=30.0, spots=2)
+    cameras, atmospheres, lights = staged(gpu, inp)
+    lut = ((128, 32), (128, 64))
+    comm = rowtile.Comm(0, 1, 0)
+    sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=lut[0], skyview_extent=lut[1])
+    alias = sky.skyviewLUT_tensor()
+    target = gpu.pl.SceneTexture(W, H, debug=True)
+    deferred = gpu.pl.DeferredShadingPipeline((W, H), max_spot_lights=2, max_shadow_maps=0)
+    deferred.recordDrawCommands(None, inp.rect, target, 1, lights, inp.spots, 0, cameras, inp.synthetic.fill)
+    prior = target.color.clone()
+    sky.recordDrawCommands(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    plain = target.debug.cpu().numpy().copy()
+
+    # a slice that is NOT the whole LUT, then the rest: the last launch describes rows [32, 64) only, this rank contributes
+    # rows [0, 64) -> "unknown" (1); a launch over exactly the contributed rows -> known and clean (0)
+    sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, 0, 32)
+    sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, 32, 64)
+    comm.allgather_skyview_lut(sky).wait()
+    torch.cuda.synchronize()
+    assert _slut_status_word(gpu, sky) == 1
+    sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, 0, 64)
+    comm.allgather_skyview_lut(sky).wait()
+    torch.cuda.synchronize()
+    assert _slut_status_word(gpu, sky) == 0
+    target.color.copy_(prior)
+    sky.recordComposite(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    assert (target.debug.cpu().numpy().view(np.uint32) == plain.view(np.uint32)).all()
+
+    # texels of unknown provenance
+    tlut = sky.download_lut(sky.transmittanceLUT()).copy()
+    alias[: lut[1][1] // 2].fill_(float("nan"))
+    torch.cuda.synchronize()
+    slut = alias.cpu().numpy().copy()
+    sky.invalidateLUTs(gpu.abi.SZG_LUT_SKYVIEW)
+    comm.allgather_skyview_lut(sky).wait()
+    torch.cuda.synchronize()
+    assert _slut_status_word(gpu, sky) == 1
+    target.color.copy_(prior)
+    sky.recordComposite(None, target, inp.rect, deferred.gbuffer(), deferred.shadowMaps(), 0, atmospheres, 0, cameras, 0, lights)
+    torch.cuda.synchronize()
+    got = target.debug.cpu().numpy()
+    frame = gpu.ob.HostFrame(W, H)
+    gpu.ob.gbuffer_fill(frame, inp.rect, None, inp.cam, inp.synthetic.fill, threads=8)
+    gpu.ob.lights(frame, inp.rect, None, None, inp.cam, inp.dirs, 2, 1, inp.spots, 2, threads=8)
+    gpu.ob.composite(frame, inp.rect, None, None, inp.atm, inp.cam, inp.dirs, 0, tlut, slut, threads=8)
+    assert (np.isnan(got) == np.isnan(frame.debug)).all()
+    ok = ~np.isnan(got)
+    assert np.isnan(got).any() and (got[ok].view(np.uint32) == frame.debug[ok].view(np.uint32)).all()
+    comm.destroy()
+    deferred.cleanup()
+    sky.destroy()
+
+
 def test_texels_written_through_a_kept_pointer_are_rescanned_after_invalidate(gpu):
     """ADVICE (round 1): the pipeline keeps a status word per LUT (sky-view: "every texel finite") that lets the composite
     leave samples of non-metal pixels unevaluated. A caller that writes texels through a pointer it kept must say so
