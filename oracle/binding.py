@@ -70,7 +70,9 @@ def lib():
     """The oracle with the GLSL built-ins pinned to include/szg/fpmath.h (the parity checker)."""
     global _LIB
     if _LIB is None:
-        _LIB = _load("libszg_oracle.so")
+        # SZG_ORACLE_LITERAL=1 (together with SZG_HIP_LIBRARY=.../libszg_hip_literal.so): the whole test suite and every sweep
+        # tool then compare the two LITERAL builds - the pair that is pinned against the reference's SPIR-V
+        _LIB = lib_literal() if os.environ.get("SZG_ORACLE_LITERAL") == "1" else _load("libszg_oracle.so")
     return _LIB
 
 

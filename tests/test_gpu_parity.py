@@ -1275,7 +1275,7 @@ def _slut_status_word(gpu, sky):
     word = gpu.abi.Image()
     word.data = im.data + im.width * im.height * 16
     word.width, word.height, word.pitch_bytes, word.format = 1, 1, 16, im.format
-    return int(gpu.pl._memcpy2d_from(word, 4, 1).cpu().numpy().view(np.uint32)[0])
+    return int(gpu.pl._memcpy2d_from(word, 4, 1).cpu().numpy().view(np.uint32).ravel()[0])
 
 
 def test_slice_status_travels_with_the_lut_all_gather(gpu):
