@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
         // the reference). It cannot when the extinction is bounded away from 0 along every ray of the shell
         // (Atm::extModerate), the transmittance LUT is moderate, and both the camera (whose sky-view LUT is sampled)
         // and the surface (origin of the reflection ray) lie inside the shell, and the reflection direction itself is finite
-        // (it is built from the G-buffer normal; found by tools/random_sweep_mesh_frames.py: a NaN normal from a degenerate
+        // (it is built from the G-buffer normal; found by tests/sweeps/random_sweep_mesh_frames.py: a NaN normal from a degenerate
         // triangle leaves the sun term at 0 through the clamps but makes the environment sample NaN); otherwise the term
         // is evaluated.
         float const cameraR2 = dot(position, position), surfaceR2 = dot(surfacePosition, surfacePosition);

@@ -1,9 +1,9 @@
 """Random parity sweep on the GPU box: frames with random extents, LUT sizes, cameras, sun elevations, atmosphere edits,
 spot-light parameters, shadow maps and row tiles, GPU vs oracle bit for bit (NaN patterns included).
-usage: python tools/random_sweep_frames.py FIRST_SEED LAST_SEED [tiny]   (400 seeds take ~15 s; "tiny": degenerate LUT extents,
+usage: python tests/sweeps/random_sweep_frames.py FIRST_SEED LAST_SEED [tiny]   (400 seeds take ~15 s; "tiny": degenerate LUT extents,
 2 ... 7 texels a side, whose marches do produce NaN texels in sane atmospheres)"""
 import sys, numpy as np, torch, ctypes as C
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from tests import util
 from tests.test_gpu_parity import staged
 from oracle import binding as ob

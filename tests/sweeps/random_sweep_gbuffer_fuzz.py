@@ -3,7 +3,7 @@ pixels, with NaN, +-inf, zeros, negative values, denormals, huge and out-of-rang
 plane (diffuse incl. its alpha flag, specular incl. black = SURVEY Q6, normal, world position incl. underground and
 planet-scale values, ORM) and in the depth buffer (geometry flagged as sky and the reverse). lights + atmosphere on the GPU
 vs the oracle on the same planes: the fp32 frame bit-identical including the NaN pattern, the RGBA16 image equal.
-usage: python tools/random_sweep_gbuffer_fuzz.py FIRST_SEED LAST_SEED"""
+usage: python tests/sweeps/random_sweep_gbuffer_fuzz.py FIRST_SEED LAST_SEED"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import binding as ob
 from syzygy_amd import abi, pipelines as pl, scene
 from tests import util

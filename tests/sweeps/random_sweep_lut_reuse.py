@@ -3,9 +3,9 @@ driven through a random walk of frames - each frame keeps the previous parameter
 or one dword of the atmosphere block (sun direction, a coefficient, a NaN), or scribbles over a LUT through a kept pointer and
 says so - and after every frame both of its LUTs must equal, bit for bit, the LUTs a FRESH pipeline computes from the same
 blocks. The staged buffers are shared and never synchronised between frames (frames in flight).
-usage: python tools/random_sweep_lut_reuse.py FIRST_SEED LAST_SEED"""
+usage: python tests/sweeps/random_sweep_lut_reuse.py FIRST_SEED LAST_SEED"""
 import sys, numpy as np, torch
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from tests import util
 from syzygy_amd import abi, pipelines as pl, scene
 

@@ -3,7 +3,7 @@ transmittance + sky-view LUTs -> composite, GPU (recordDrawCommandsMeshes + SkyV
 same chain. Random cameras, sun elevations, spot counts and scenes (default scene, triangle soups, hostile geometry with
 NaN / inf / degenerate primitives, whose G-buffer NaNs must poison the same pixels on both sides).
 The fp32 frame must be bit-identical (NaN == NaN) and the RGBA16 image within 1 LSB.
-usage: python tools/random_sweep_mesh_frames.py FIRST_SEED LAST_SEED"""
+usage: python tests/sweeps/random_sweep_mesh_frames.py FIRST_SEED LAST_SEED"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import binding as ob
 from syzygy_amd import abi, lib, meshes, pipelines as pl, scene
 from tests import util

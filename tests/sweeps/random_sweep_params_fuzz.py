@@ -3,7 +3,7 @@ spot-light blocks are overwritten with NaN, +-inf, zeros, negative, denormal, hu
 patterns (planet radius 0, atmosphere inside the planet, zero or NaN sun direction, singular matrices, zero falloff...).
 Every pass on the GPU vs the oracle on the same blocks: both LUTs, the lights pass and the final frame bit-identical including
 the NaN pattern. Exercises the generic (non-lean) paths and every guard of the exact shortcuts.
-usage: python tools/random_sweep_params_fuzz.py FIRST_SEED LAST_SEED [extensions]   ("extensions": the opt-in LUTs too)"""
+usage: python tests/sweeps/random_sweep_params_fuzz.py FIRST_SEED LAST_SEED [extensions]   ("extensions": the opt-in LUTs too)"""
 import ctypes as C
 import os
 import sys
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import binding as ob
 from syzygy_amd import abi, pipelines as pl, scene
 from tests import util

@@ -1,8 +1,8 @@
 """Random parity sweep of the compute rasteriser on the GPU box: random cameras, extents, row tiles and scenes (default
 scene, triangle soups up to 24 k primitives, hostile geometry), GPU vs oracle bit for bit.
-usage: python tools/random_sweep_raster.py FIRST_SEED LAST_SEED"""
+usage: python tests/sweeps/random_sweep_raster.py FIRST_SEED LAST_SEED"""
 import sys, numpy as np, torch, ctypes as C
-sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from tests import util
 from tests.test_raster import _soup, _hostile_scene, _planes_equal
 from oracle import binding as ob

@@ -2,7 +2,7 @@
 matrices, model matrices (and their inverse transposes) and vertex records (positions, normals, uvs) are overwritten with
 NaN, +-inf, zeros, negative, denormal, huge values and raw random bit patterns; textures of odd shapes (1 x N, N x 1, 3 x 5).
 G-buffer raster and shadow raster, GPU vs oracle bit for bit (NaN == NaN).
-usage: python tools/random_sweep_raster_fuzz.py FIRST_SEED LAST_SEED"""
+usage: python tests/sweeps/random_sweep_raster_fuzz.py FIRST_SEED LAST_SEED"""
 import ctypes as C
 import os
 import sys
@@ -10,7 +10,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import binding as ob
 from syzygy_amd import abi, lib, meshes, pipelines as pl, scene
 from syzygy_amd.pipelines import _memcpy2d_from

@@ -1,7 +1,7 @@
 """Random parity sweep of the shadow-map rasteriser on the GPU box: random spot lights (position, direction, field of view,
 near / far), depth-bias settings, map sizes and scenes (default scene, triangle soups, hostile geometry), GPU vs oracle
 bit for bit.
-usage: python tools/random_sweep_shadow.py FIRST_SEED LAST_SEED"""
+usage: python tests/sweeps/random_sweep_shadow.py FIRST_SEED LAST_SEED"""
 import ctypes as C
 import os
 import sys
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import binding as ob
 from syzygy_amd import abi, lib, meshes, pipelines as pl, scene
 from syzygy_amd.pipelines import _memcpy2d_from

@@ -100,18 +100,18 @@ def test_example_render_gltf_runs(tmp_path):
                                              ("random_sweep_raster_fuzz.py", 100, 130),
                                              ("random_sweep_raster_fuzz.py", 1375, 1390), ("random_sweep_raster_fuzz.py", 2920, 2935)])
 def test_random_sweep_tools_find_nothing(tool, first, last, extra=()):
-    """tools/random_sweep_*.py are how the round's rare parity bugs were found; a slice of each — the seed
+    """tests/sweeps/random_sweep_*.py are how the round's rare parity bugs were found; a slice of each — the seed
     ranges that once held mismatches — runs here so that the tools keep working and those cases stay fixed."""
-    r = subprocess.run([sys.executable, os.path.join("tools", tool), str(first), str(last), *extra], cwd=ROOT, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join("tests", "sweeps", tool), str(first), str(last), *extra], cwd=ROOT, capture_output=True, text=True,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "mismatching seeds: 0" in r.stdout, r.stdout[-2000:]
 
 
 def test_random_sweep_of_lut_reuse():
-    """tools/random_sweep_lut_reuse.py: a long-lived pipeline with LUT reuse on a random walk of parameter changes, repeats,
+    """tests/sweeps/random_sweep_lut_reuse.py: a long-lived pipeline with LUT reuse on a random walk of parameter changes, repeats,
     scribbled texels and invalidations; after every frame its LUTs equal a fresh pipeline's."""
-    r = subprocess.run([sys.executable, "tools/random_sweep_lut_reuse.py", "0", "40"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "tests/sweeps/random_sweep_lut_reuse.py", "0", "40"], cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "done, mismatching seeds: 0" in r.stdout, r.stdout[-2000:]
 

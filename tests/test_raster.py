@@ -405,7 +405,7 @@ def test_gbuffer_raster_fullscreen_fan_is_watertight(gpu):
 @pytest.mark.parametrize("z", [0.0, -0.0, 1.0e-45])
 def test_gbuffer_raster_depth_equal_to_the_clear_value_is_not_a_fragment(gpu, z):
     """GREATER against the cleared 0 (deferred.cpp:383-386): a primitive whose depth is exactly 0 (in the wild: the underflow
-    of a huge, far primitive; found by tools/random_sweep_raster.py seed 21607) covers pixels but produces no fragment,
+    of a huge, far primitive; found by tests/sweeps/random_sweep_raster.py seed 21607) covers pixels but produces no fragment,
     in front of or behind a real one; the smallest positive depth does."""
     W, H = 67, 45
     fan = _fullscreen_fan(z=z)
@@ -542,7 +542,7 @@ def test_frame_from_real_meshes_matches_oracle_chain(gpu):
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed", [1465, 1484, 1497])
 def test_frame_from_hostile_meshes_poisons_the_same_pixels(gpu, seed):
-    """The whole chain on degenerate geometry (tools/random_sweep_mesh_frames.py found these): a zero-area or constant-uv
+    """The whole chain on degenerate geometry (tests/sweeps/random_sweep_mesh_frames.py found these): a zero-area or constant-uv
     triangle writes a NaN normal into the G-buffer. The sun term survives through its clamps, but the metal reflection's
     environment sample is NaN and `0 * NaN` poisons the pixel in the reference even for metallic == 0, so the composite
     may not skip that term. fp32 frame bit-identical including the NaN pattern."""
