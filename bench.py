@@ -91,7 +91,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     if args.same_device:
-        if args.backend != "gloo":
+        if args.backend != "gloo" and not os.environ.get("SZG_RCCL_LIBRARY"):
+            # (tests/cpp/mock_rccl.cpp, named by SZG_RCCL_LIBRARY, stands in for RCCL in the one-GPU rehearsal of the C-ABI
+            # collectives: it stages through host memory and does not mind ranks sharing a device)
             raise SystemExit("--same-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
         local_rank = 0
     torch.cuda.set_device(local_rank)

@@ -15,8 +15,8 @@ CONTRACT_KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
                  "dtype", "data", "config", "roofline"]
 
 
-def _run(cmd):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+def _run(cmd, env=None):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", **(env or {}))
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [line for line in r.stdout.splitlines() if line.strip()]
@@ -49,6 +49,26 @@ def test_bench_under_an_external_launcher_and_forced_tiling_on_rccl():
                 "--no-cpu-baseline"])
     assert one["config"]["collectives"] == "nccl" and one["config"]["parallelism"] == "rowtile1+gather"
     assert one["image_checksum"] == two["image_checksum"]
+
+
+@pytest.mark.parametrize("ranks", [2, 4])
+def test_n_rank_frame_through_the_c_abi_collectives_on_one_gpu(ranks):
+    """The multi-rank frame loop through the C-ABI's OWN collective entry points (szg_rowtile_comm_*, szg_rowtile_gather,
+    szg_skyview_allgather_lut_rows with the status-word exchange) with N real processes on one GPU. RCCL itself cannot run
+    there (it refuses two ranks on a device), so tests/cpp/mock_rccl.cpp stands in for librccl.so behind SZG_RCCL_LIBRARY:
+    same entry points, same in-place / root-only contracts, bytes staged through a mapped file. Everything above that
+    boundary is the product's code: the communicator pair, byte offsets of tiles and LUT slices, the cyclic row blocks, the
+    two frames in flight, the compose. The composed 8K image must have the checksum of the single-GPU frame."""
+    subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "libmock_rccl.so"], check=True)
+    env = {"SZG_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "libmock_rccl.so")}
+    many = _run([sys.executable, "bench.py", "--gpus", str(ranks), "--backend", "nccl", "--same-device", "--steps", "2", "--warmup", "1",
+                 "--no-cpu-baseline"], env=env)
+    cfg = many["config"]
+    assert many["n_gpus"] == ranks and cfg["parallelism"] == f"rowtile{ranks}+gather" and cfg["collectives"] == "nccl"
+    assert cfg["collective_api"].startswith("szg_rowtile_comm") and cfg["rccl_ranks"] == ranks
+    with open(os.path.join(ROOT, "profiles", "r02_bench_c4.json")) as f:
+        single = json.load(f)
+    assert many["image_checksum"] == single["image_checksum"]
 
 
 def test_bench_roofline_names_the_dominant_kernel_of_each_workload():
