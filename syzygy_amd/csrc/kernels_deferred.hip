@@ -288,7 +288,7 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
         r.leanOK = (r.isSpot != 0u && finite && rowsModerate && inRange(r.falloffDistance, lo, hi) && inRange(r.falloffFactor, lo, hi)) ? 1u : 0u;
         r.pad[0] = r.leanOK; // "cullable"
     }
-    r.pad[1] = 0u;
+    r.rcpFalloffDistance = r.leanOK != 0u ? rcpN(r.falloffDistance) : 0.0f;
     out[i] = r;
 }
 
@@ -360,7 +360,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
         float const distanceUV = clampf(sqrtU(lean, q) * 2.0f, 0.0f, 1.0f);
         edgeSoftening = 1.0f - distanceUV * distanceUV;
         float const dist = sqrtU(lean, d2);
-        float const nd = lean ? divN(dist, L.falloffDistance) : dist / L.falloffDistance;
+        float const nd = lean ? divR(dist, L.falloffDistance, L.rcpFalloffDistance) : dist / L.falloffDistance;
         lightFalloff = L.falloffFactor * nd * nd;
     }
     float shadow = 1.0f;
