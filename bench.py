@@ -211,13 +211,18 @@ def main():
             # LUTs first: every rank computes 1/N of the sky-view LUT rows, and the all-gather of the slices runs
             # while the lights pass (which needs no LUT) is shading
             sky.recordTransmittance(None, 0, atmospheres)
-            b, en = sky.lutRowSlice(rank, nranks)
-            sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, b, en)
-            if comm is not None:
-                lut_work = comm.allgather_skyview_lut(sky)
+            if sky.desc.skyview_height % nranks != 0:
+                # the LUT's rows do not divide over the ranks: every rank computes the whole LUT (no second collective)
+                sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+                lut_work = rowtile._Done()
             else:
-                lut_work = rowtile.allgather_lut(sky_lut, rank, nranks, group=torch_group, async_op=True, force=True)
-                sky.invalidateLUTs(abi.SZG_LUT_SKYVIEW)  # texels written through the aliased tensor
+                b, en = sky.lutRowSlice(rank, nranks)
+                sky.recordSkyViewLUTRows(None, 0, atmospheres, 0, cameras, b, en)
+                if comm is not None:
+                    lut_work = comm.allgather_skyview_lut(sky)
+                else:
+                    lut_work = rowtile.allgather_lut(sky_lut, rank, nranks, group=torch_group, async_op=True, force=True)
+                    sky.invalidateLUTs(abi.SZG_LUT_SKYVIEW)  # texels written through the aliased tensor
             if e:
                 e[1].record()
                 e[2].record()

@@ -352,17 +352,23 @@ struct SkyViewComputePipeline
     {
         uint32_t begin = 0, end = 0;
         (void)szg_skyview_record_transmittance(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress());
-        if (szg_skyview_lut_row_slice(m_handle, tile.rank, tile.nranks, &begin, &end) != SZG_OK)
+        if (szg_skyview_lut_row_slice(m_handle, tile.rank, tile.nranks, &begin, &end) == SZG_OK)
         {
-            return;
+            (void)szg_skyview_record_skyview_lut_rows(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
+                                                      cameras.deviceAddress(), begin, end);
+            (void)hipEventRecord(scratchEvent, cmd);
+            (void)hipStreamWaitEvent(lutStream, scratchEvent, 0);
+            (void)szg_skyview_allgather_lut_rows(m_handle, comm, lutStream);
+            (void)hipEventRecord(scratchEvent, lutStream);
+            (void)hipStreamWaitEvent(cmd, scratchEvent, 0);
         }
-        (void)szg_skyview_record_skyview_lut_rows(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
-                                                  cameras.deviceAddress(), begin, end);
-        (void)hipEventRecord(scratchEvent, cmd);
-        (void)hipStreamWaitEvent(lutStream, scratchEvent, 0);
-        (void)szg_skyview_allgather_lut_rows(m_handle, comm, lutStream);
-        (void)hipEventRecord(scratchEvent, lutStream);
-        (void)hipStreamWaitEvent(cmd, scratchEvent, 0);
+        else
+        {
+            // the LUT's rows do not divide over the ranks (every rank sees that alike): each rank computes the whole LUT,
+            // as the single-GPU frame does, and the optional second collective is skipped
+            (void)szg_skyview_record_skyview_lut(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
+                                                 cameras.deviceAddress());
+        }
         (void)szg_skyview_record_composite(m_handle, cmd, &sceneTexture.texture(), drawRect, &tile, &gbuffer, &shadowMaps,
                                            atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex, cameras.deviceAddress(),
                                            sunLightIndex, lights.deviceAddress());

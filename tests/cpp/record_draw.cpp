@@ -1,8 +1,13 @@
 // record_draw.cpp — a Renderer::recordDraw-style caller (reference renderer.cpp:278-443)
 // written against include/szg/pipelines.hpp. Renders one frame and writes the RGBA16 scene
 // colour to argv[1]; tests/test_gpu_cpp_shim.py compares it with the Python path / oracle.
+#include <unistd.h>
+
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "szg/assets.hpp"
@@ -166,7 +171,7 @@ int main(int argc, char** argv)
 {
     if (argc < 4)
     {
-        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes | tiled | gltf <file> [loader flags] | scene [ticks]]\n");
+        std::fprintf(stderr, "usage: record_draw out.bin width height [meshes | tiled [rank nranks idfile] | gltf <file> [loader flags] | scene [ticks]]\n");
         return 2;
     }
     uint32_t const W = (uint32_t)std::atoi(argv[2]), H = (uint32_t)std::atoi(argv[3]);
@@ -179,6 +184,11 @@ int main(int argc, char** argv)
     // "tiled": the row-tiled multi-GPU frame as ONE rank of a world of one - the C-ABI's communicator (RCCL), the LUT row
     // slice + all-gather, the tile gather to the root and the compose kernel, all from C++ (no Python, no torch)
     bool const tiled = argc > 4 && std::strcmp(argv[4], "tiled") == 0;
+    // "tiled rank nranks idfile": one of nranks processes; rank 0 creates the communicator id and leaves it in `idfile`, the
+    // others pick it up there (a launcher's job in an engine), rank 0 gathers, composes and writes the frame
+    uint32_t const tileRank = tiled && argc > 7 ? (uint32_t)std::atoi(argv[5]) : 0u;
+    uint32_t const tileRanks = tiled && argc > 7 ? (uint32_t)std::atoi(argv[6]) : 1u;
+    const char* const idFile = tiled && argc > 7 ? argv[7] : nullptr;
 
     // scene -> packed blocks (renderer.cpp:302-342)
     szg_camera camera;
@@ -298,12 +308,58 @@ int main(int argc, char** argv)
     {
         unsigned char id[SZG_ROWTILE_COMM_ID_BYTES];
         szg_rowtile_comm_t* comm = nullptr;
-        if (szg_rowtile_comm_unique_id(id) != SZG_OK || szg_rowtile_comm_create(&comm, 0, 1, id, 0) != SZG_OK)
+        if (tileRank == 0u)
+        {
+            if (szg_rowtile_comm_unique_id(id) != SZG_OK)
+            {
+                std::fprintf(stderr, "communicator id: %s\n", szg_last_error());
+                return 1;
+            }
+            if (idFile != nullptr)
+            {
+                std::string const tmp = std::string(idFile) + ".tmp";
+                FILE* f = std::fopen(tmp.c_str(), "wb");
+                if (f == nullptr || std::fwrite(id, 1, sizeof id, f) != sizeof id || std::fclose(f) != 0 || std::rename(tmp.c_str(), idFile) != 0)
+                {
+                    std::fprintf(stderr, "cannot publish the communicator id\n");
+                    return 1;
+                }
+            }
+        }
+        else
+        {
+            bool have = false;
+            for (int spin = 0; spin < 6000 && !have; spin++)
+            {
+                FILE* f = std::fopen(idFile, "rb");
+                if (f != nullptr)
+                {
+                    have = std::fread(id, 1, sizeof id, f) == sizeof id;
+                    std::fclose(f);
+                }
+                if (!have)
+                {
+                    usleep(10000);
+                }
+            }
+            if (!have)
+            {
+                std::fprintf(stderr, "rank %u: no communicator id in %s\n", tileRank, idFile);
+                return 1;
+            }
+        }
+        if (szg_rowtile_comm_create(&comm, (int)tileRank, (int)tileRanks, id, 0) != SZG_OK)
         {
             std::fprintf(stderr, "communicator: %s\n", szg_last_error());
             return 1;
         }
-        szg_rowtile const tile{8u, 0u, 1u, szg_rowtile_local_rows(H, 8u, 0u, 1u)};
+        szg_rowtile const tile{8u, tileRank, tileRanks, szg_rowtile_local_rows(H, 8u, tileRank, tileRanks)};
+        // every rank sends the same number of bytes: the largest share of rows any rank holds
+        uint32_t strideRows = 0;
+        for (uint32_t r = 0; r < tileRanks; r++)
+        {
+            strideRows = std::max(strideRows, szg_rowtile_local_rows(H, 8u, r, tileRanks));
+        }
         hipStream_t side = nullptr;
         hipEvent_t ev = nullptr;
         (void)hipStreamCreate(&side);
@@ -312,15 +368,15 @@ int main(int argc, char** argv)
         skyView->recordDrawCommandsTiled(cmd, side, ev, comm, *sceneTexture, sceneSubregion, deferred.gbuffer(), deferred.shadowMaps(), 0,
                                          atmospheres, 0, cameras, 0, lights, tile);
         // THE collective: every rank's packed rows to rank 0, then the row scatter into the frame
-        size_t const tileBytes = (size_t)sceneTexture->color().pitch_bytes * tile.local_rows;
+        size_t const tileBytes = (size_t)sceneTexture->color().pitch_bytes * strideRows;
         void *gathered = nullptr, *composed = nullptr;
-        (void)hipMalloc(&gathered, tileBytes);
+        (void)hipMalloc(&gathered, tileBytes * tileRanks);
         (void)hipMalloc(&composed, (size_t)W * H * 8);
         szg_image const frame{composed, W, H, W * 8u, SZG_FORMAT_RGBA16_UNORM};
         int rc = szg_rowtile_gather(comm, cmd, sceneTexture->color().data, tileBytes, gathered, 0);
-        if (rc == SZG_OK)
+        if (rc == SZG_OK && tileRank == 0u)
         {
-            rc = szg_compose_rowtiles(cmd, gathered, tileBytes, 1u, tile.block_rows, &frame, W, H);
+            rc = szg_compose_rowtiles(cmd, gathered, tileBytes, tileRanks, tile.block_rows, &frame, W, H);
         }
         if (rc != SZG_OK || hipStreamSynchronize(cmd) != hipSuccess)
         {
@@ -328,6 +384,11 @@ int main(int argc, char** argv)
             return 1;
         }
         std::printf("ranks %d\n", szg_rowtile_comm_size(comm));
+        if (tileRank != 0u)
+        {
+            szg_rowtile_comm_destroy(comm);
+            return 0; // the frame leaves through rank 0
+        }
         (void)hipMemcpy2DAsync(sceneTexture->color().data, sceneTexture->color().pitch_bytes, composed, (size_t)W * 8, (size_t)W * 8, H,
                                hipMemcpyDeviceToDevice, cmd);
         (void)hipStreamSynchronize(cmd);

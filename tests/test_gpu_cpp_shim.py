@@ -269,3 +269,29 @@ def test_cpp_tiled_frame_through_the_c_abi_collectives(tmp_path):
     a = np.fromfile(plain, dtype=np.uint16)
     b = np.fromfile(tiled, dtype=np.uint16)
     assert a.shape == b.shape and (a == b).all()
+
+
+@pytest.mark.parametrize("ranks", [2, 3])
+def test_cpp_n_rank_tiled_frame_through_the_c_abi_collectives(tmp_path, ranks):
+    """The same C++ caller as N processes (no Python, no torch inside them): rank 0 publishes the communicator id in a file,
+    every rank renders its cyclic 8-row blocks, the sky-view LUT slices and their status words are all-gathered, the tiles
+    gathered to rank 0 and composed. The processes share the one GPU of the box, where RCCL cannot run two ranks, so
+    tests/cpp/mock_rccl.cpp stands in for librccl.so (SZG_RCCL_LIBRARY); everything else is the product's C-ABI. The frame
+    must equal the plain single-process frame bit for bit. With 3 ranks the 1024 rows of the sky-view LUT do not divide: every
+    rank then computes the whole LUT and the optional second collective is skipped (pipelines.hpp) - same frame."""
+    exe = os.path.join(HERE, "cpp", "record_draw")
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpp"), "record_draw", "libmock_rccl.so"], check=True)
+    env = dict(os.environ, SZG_RCCL_LIBRARY=os.path.join(HERE, "cpp", "libmock_rccl.so"))
+    W, H = 200, 240
+    plain, tiled, idfile = tmp_path / "plain.bin", tmp_path / "tiled.bin", tmp_path / "comm.id"
+    r = subprocess.run([exe, str(plain), str(W), str(H)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    procs = [subprocess.Popen([exe, str(tiled if k == 0 else tmp_path / f"unused{k}.bin"), str(W), str(H), "tiled", str(k), str(ranks), str(idfile)],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(ranks)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se + so
+        assert f"ranks {ranks}" in so
+    a = np.fromfile(plain, dtype=np.uint16)
+    b = np.fromfile(tiled, dtype=np.uint16)
+    assert a.shape == b.shape and (a == b).all()
