@@ -286,9 +286,9 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
                             fabsf(r.position[0]) <= hi && fabsf(r.position[1]) <= hi && fabsf(r.position[2]) <= hi &&
                             fabsf(r.dir[0]) <= 2.0f && fabsf(r.dir[1]) <= 2.0f && fabsf(r.dir[2]) <= 2.0f;
         r.leanOK = (r.isSpot != 0u && finite && rowsModerate && inRange(r.falloffDistance, lo, hi) && inRange(r.falloffFactor, lo, hi)) ? 1u : 0u;
-        r.pad[0] = r.leanOK; // "cullable"
     }
     r.rcpFalloffDistance = r.leanOK != 0u ? rcpN(r.falloffDistance) : 0.0f;
+    r.falloffBound = r.falloffFactor * r.rcpFalloffDistance * r.rcpFalloffDistance;
     out[i] = r;
 }
 
@@ -319,7 +319,10 @@ SZG_DEV float sqrtU(bool lean, float x) { return lean ? sqrtN(x) : sqrtf(x); }
 // One light's term of the sum (lights.comp:141-161), exact.
 // `clip`: shadowMatrix * vec4(position, 1), rows x, y, w summed left to right (projectRows below: the cone test and the
 // exact evaluation share one evaluation of the three rows; R[k] * 1.0f of the shader's product is R[k] itself)
-SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool positionModerate, V3 viewDirection, bool cullable, V3 clip)
+// `backCull` (per lane): the pixel's own factors are of ordinary magnitude (k_lights, pixelModerate), so that a term whose last
+// factor clamp(N.L, 0, 1) is 0 is an exact zero and its BRDF (half of the cost of a lit pair) need not be evaluated.
+SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool positionModerate, V3 viewDirection, bool cullable, V3 clip,
+                             bool backCull)
 {
     const float* R = L.shadowRows;
     float const cx = clip.x, cy = clip.y, cw = clip.z;
@@ -327,6 +330,21 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     V3 const lightDir = mk3(L.dir[0], L.dir[1], L.dir[2]);
     V3 const toLight = mk3(L.position[0], L.position[1], L.position[2]) - m.position;
     float const d2 = dot(toLight, toLight);
+    // The surface faces away from the light: clamp(dot(N, L), 0, 1) = 0 (also for a NaN, fmax(NaN, 0) = 0) is the last factor
+    // of ((occlusion * brdf) * spectral) * clamp(N.L) (lights.comp:106-107), so the term is +-0 - and sum + (+-0) == sum, the sum
+    // being never -0 - provided the other factors are finite numbers whose product does not overflow:
+    //   |occlusion * brdf| < 2^36 for a pixel of ordinary magnitude (k_lights, pixelModerate; clamp() turns a NaN half
+    //   vector into 0, so brdf is a number whatever the directions are);
+    //   spectral = ((colour * strength / falloff) * edge) * shadow with colour * strength <= 2^30 (k_light_prep, leanOK), edge and
+    //   shadow in [0, 1] whatever the projected coordinates are, and falloff = factor * (dist / falloffDistance)^2 >= 2^-30:
+    //   tested as falloffBound * d^2 >= 2^-28, the same quantity up to rounding, with a factor of 4 to spare (an infinite
+    //   falloff gives spectral = 0).
+    // Then nothing of this light needs evaluating for the pixel: a quarter of the lit pixel-light pairs of the bench scenes.
+    float const ndl = dot(m.normal, lightDir);
+    if (backCull && cullable && isSpot && L.leanOK != 0u && !(ndl > 0.0f) && L.falloffBound * d2 >= 0x1p-28f)
+    {
+        return splat(0.0f);
+    }
     V3 const hs = lightDir + viewDirection;
     float const hd = dot(hs, hs);
     // Operand ranges of the lean ops used below: w of the projected position, squared distance to the light
@@ -401,7 +419,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     V3 const fresnel = m.reflectance + (splat(1.0f) - m.reflectance) * p;
     V3 const brdf = mix(m.diffuse, specular, fresnel);
     // lights.comp:106-107
-    return ((m.occlusion * brdf) * spectral) * clampf(dot(m.normal, lightDir), 0.0f, 1.0f);
+    return ((m.occlusion * brdf) * spectral) * clampf(ndl, 0.0f, 1.0f);
 }
 
 // The three rows of the shadow matrix the cone test needs (x, y, w) + the spot flag: what is prefetched.
@@ -478,6 +496,12 @@ __global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug
                                  fabsf(m.diffuse.z) <= big && fabsf(m.reflectance.x) <= big && fabsf(m.reflectance.y) <= big &&
                                  fabsf(m.reflectance.z) <= big && fabsf(m.occlusion) <= big && fabsf(m.normalization) <= big &&
                                  fabsf(m.specularPower) <= big;
+        // ... and of ordinary magnitude (every real material: roughness in [0, 1] gives a specular power <= 160): then
+        // |occlusion * mix(diffuse, specular, fresnel)| < 2^36, see lightContribution's back-face test
+        bool const pixelModerate = pixelFinite && fabsf(m.diffuse.x) <= 0x1p16f && fabsf(m.diffuse.y) <= 0x1p16f &&
+                                   fabsf(m.diffuse.z) <= 0x1p16f && fabsf(m.reflectance.x) <= 4.0f && fabsf(m.reflectance.y) <= 4.0f &&
+                                   fabsf(m.reflectance.z) <= 4.0f && fabsf(m.occlusion) <= 0x1p16f && fabsf(m.normalization) <= 0x1p8f &&
+                                   fabsf(m.normal.x) <= 0x1p16f && fabsf(m.normal.y) <= 0x1p16f && fabsf(m.normal.z) <= 0x1p16f;
         // Light records are wave-uniform: they are fetched with scalar loads and live in SGPRs. Culling is decided per
         // wave: when some pixel of the wave has a non-finite factor the whole wave evaluates every light (no term of its
         // sum may be dropped); the flag of the light itself is wave-uniform anyway.
@@ -487,13 +511,13 @@ __global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug
         {
             const LightRec* __restrict__ L = lights + i;
             LightCull const cur = loadCull(L); // (prefetching light i+1's rows here measured 20 % slower)
-            bool const cullable = waveFinite && L->pad[0] != 0u;
+            bool const cullable = waveFinite && L->leanOK != 0u;
             V3 const clip = projectRows(cur, m.position);
             if (cur.isSpot != 0u && cullable && surelyOutsideCone(clip))
             {
                 continue;
             }
-            sum = sum + lightContribution(*L, m, positionModerate, viewDirection, cullable, clip);
+            sum = sum + lightContribution(*L, m, positionModerate, viewDirection, cullable, clip, pixelModerate);
         }
     }
     row_ptr<uint2>(color, y)[x] = pack_unorm16x4(sum.x, sum.y, sum.z, 1.0f);

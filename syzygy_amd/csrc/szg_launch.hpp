@@ -24,7 +24,8 @@ struct LightRec
     unsigned mapWidth, mapHeight;
     unsigned mapPitchFloats;
     unsigned leanOK; // falloffDistance / falloffFactor / colour*strength of moderate magnitude (lean exact ops allowed)
-    unsigned pad[1]; // pad[0]: the light's own factors are finite and non-zero where they divide (a culled pixel's term is an exact 0)
+    // (leanOK also says: the light's own factors are finite and non-zero where they divide, so a culled pixel's term is an exact 0)
+    float falloffBound;       // falloffFactor / falloffDistance^2 when leanOK: falloffBound * d^2 ~ the light's falloff at distance d
     float rcpFalloffDistance; // rcpN(falloffDistance) when leanOK: the shared reciprocal of dist / falloffDistance (once per light, not per wave)
 };
 static_assert(sizeof(LightRec) == 144, "LightRec layout");
