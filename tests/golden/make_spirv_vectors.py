@@ -5,7 +5,7 @@ seeded inputs - together with those inputs. tests/test_spirv_pin.py then require
 oracle/libszg_oracle_literal.so) to reproduce every one of them BIT FOR BIT. That pins the oracle's dataflow - every
 operation, constant, branch and its order - against the reference's binaries instead of against a reading of the GLSL.
 
-    python tests/golden/make_spirv_vectors.py            (needs /root/reference; ~ 3 min)
+    python tests/golden/make_spirv_vectors.py            (needs /root/reference; ~ 1.5 min)
 
 What the vectors do NOT pin (stated in DESIGN.md 2): the values of the implementation-defined GLSL built-ins (exp, pow, sin,
 cos, asin, acos: both sides use include/szg/fpmath.h), the fixed-function texture filter (both sides: binary32 weights,
