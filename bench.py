@@ -512,6 +512,29 @@ def main():
                                       "frac_of_8TBps": 52 * W * H / (raster_ms / 1e3) / 1e9 / HBM_PEAK_GBS, "in_value": False}
         raster_pipe.cleanup()
 
+    if rank == 0 and extras:
+        # How far the library that was TIMED above is from the reference: tests/gpu_spirv_pin_child.py renders the inputs of
+        # tests/golden/spirv_vectors.npz (5 248 values the reference's committed SPIR-V computes when executed literally) with
+        # the same library, in a child process. north_star's bar is 1e-4 relative; the product's contraction rule
+        # (include/szg/contraction.h) is chosen so that it holds, with one UNORM16 step on the stored image.
+        import subprocess
+
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "gpu_spirv_pin_child.py")], env=dict(os.environ),
+                               capture_output=True, text=True, timeout=300)
+            pin = json.loads(r.stdout.strip().split("\n")[-1])
+            out["parity_vs_spirv_vectors"] = {
+                "library": pin["library"], "values": pin["values"],
+                "rel_max": max(pin[k + "_rel_max"] for k in ("transmittance", "skyview", "lights", "camera")),
+                "lsb_max": max(pin["lights_unorm_max_step"], pin["camera_unorm_max_step"]),
+                "per_shader_rel_max": {k: pin[k + "_rel_max"] for k in ("transmittance", "skyview", "lights", "camera")},
+                "bit_identical_values": pin["values"] - sum(pin[k + "_mismatches"] for k in ("transmittance", "skyview", "lights", "camera")),
+                "rel": "|got - want| / max(|want|, 1e-3)", "vectors": "tests/golden/spirv_vectors.npz",
+                "within_1e-4_and_1_lsb": bool(max(pin[k + "_rel_max"] for k in ("transmittance", "skyview", "lights", "camera")) <= 1e-4
+                                              and max(pin["lights_unorm_max_step"], pin["camera_unorm_max_step"]) <= 1)}
+        except Exception as e:  # the extra must never take the bench line down
+            log(f"parity_vs_spirv_vectors extra failed: {e}")
+
     if extras and "SZG_HIP_LIBRARY" not in os.environ:
         # The literal build of the same kernels (libszg_hip_literal.so: the contraction rule switched off, bit-identical to
         # the reference's SPIR-V executed literally, tests/test_gpu_spirv_pin.py), timed by a child process on the same

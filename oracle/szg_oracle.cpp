@@ -22,22 +22,26 @@
 // Numerics: every GLSL operation is evaluated in fp32 in the order written in
 // the shader; compile with -O2 -ffp-contract=off (the COMPILER contracts
 // nothing, no fast-math).
-// CONTRACTION RULE (round 2). The reference's shaders carry no `precise`
+// CONTRACTION RULE (round 3; include/szg/contraction.h). The reference's shaders carry no `precise`
 // qualifier and its committed SPIR-V not one NoContraction decoration
 // (tests/test_spv_layout.py), so a Vulkan implementation may evaluate a * b + c
 // with one rounding, and dot(), matrix * vector and mix() are single SPIR-V
 // instructions (OpDot, OpMatrixTimesVector, FMix) whose inner arithmetic is the
-// implementation's; texture filtering is fixed function altogether. This
-// restatement, like every shader compiler for real hardware, therefore uses
-// fused multiply-adds - explicitly (fmaf), at exactly these places, keeping the
-// shader's order of additions, and the HIP kernels do the same at the same places:
-//   dot(a, b)            = fma(az, bz, fma(ay, by, ax * bx))
-//   (M * v).row          = fma(m3, vw, fma(m2, vz, fma(m1, vy, m0 * vx)))
-//   mix(a, b, w)         = fma(b, w, a * (1 - w))
-//   bilinear fetch       = fma(w11, t11, fma(w01, t01, fma(w10, t10, w00 * t00))), texel coordinate fma(s, W, -0.5)
-//   LUT coordinate maps  = fma(x, 1 - 1/N, 0.5/N);  d = max(fma(-r, mu, sqrt(fma(r*r, fma(mu, mu, -1), Ra^2))), 0)
-//   march geometry       = origin - t * dir as fma(-t, dir, origin);  fma(2 r mu, t, t*t) + r*r;  fma(t, mu_step, r * mu_sun)
-//   march accumulation   = fma(sM, pM, sR * pR);  luminance = fma(p * s * i, t, luminance)
+// implementation's. Round 2 fused at every such place; that put results up to
+// 2.3e-3 from a literal execution of the SPIR-V, because some places feed the
+// ill-conditioned march. Round 3 names the places by SITE CLASS (one bit each of
+// SZG_CONTRACT, the same header on both sides) and fuses - explicitly, keeping
+// the shader's order of additions, identically in the HIP kernels - only the
+// classes measured on MI355X to leave all 5 248 recorded values within 1e-4
+// relative and one UNORM16 step (profiles/r03_contraction_classes.md):
+//   (M * v).row          = fma(m3, vw, fma(m2, vz, fma(m1, vy, m0 * vx)))          MATVEC
+//   mix(a, b, w)         = fma(b, w, a * (1 - w))                                   MIX
+//   texel coordinate     = fma(s, W, -0.5)                                          TEXCOORD
+//   stepRadiusMu         = fma(2 r mu, t, t*t) + r*r;  fma(t, mu_step, r * mu_sun)  STEP
+//   march accumulation   = fma(sM, pM, sR * pR);  luminance = fma(p * s * i, t, luminance)   ACCUM
+//   dot / normalize of pbrFunctions.glinl and of lights.comp                        PBRDOT, LDOT
+// Two roundings (as the SPIR-V reads) everywhere else: the other dots, the
+// bilinear sums, both LUT coordinate maps, the march's sample points.
 // Everything else is one rounding per written operation.
 // The implementation-defined GLSL built-ins (exp, pow, sin, cos,
 // asin, acos) are the pinned fp32 algorithms of include/szg/fpmath.h, or libm
@@ -54,14 +58,13 @@
 // texels and 582 + 582 pixels that tests/golden/spirv_interp.py obtained by executing the reference's COMMITTED SPIR-V
 // (transmittance_LUT / skyview_LUT / lights / camera .comp.spv) literally. Outside that pin: the values of the built-ins
 // below, the sampler / UNORM models and the contraction rule - the freedoms Vulkan leaves to an implementation.
-// The contraction rule as ONE switch: -DSZG_ORACLE_LITERAL evaluates every a * b + c of the list above with two roundings,
-// i.e. executes the shaders' SPIR-V literally (libszg_oracle_literal.so; tests/test_spirv_pin.py compares that build, bit for
-// bit, with an interpreter run over the reference's committed .spv). The default build fuses.
+// -DSZG_ORACLE_LITERAL (SZG_CONTRACT = 0) evaluates every a * b + c with two roundings, i.e. executes the shaders' SPIR-V
+// literally (libszg_oracle_literal.so; tests/test_spirv_pin.py compares that build, bit for bit, with an interpreter run
+// over the reference's committed .spv). The default build fuses the product's classes (szg/contraction.h).
 #ifdef SZG_ORACLE_LITERAL
-#define SZG_FMA(a, b, c) ((a) * (b) + (c))
-#else
-#define SZG_FMA(a, b, c) fmaf((a), (b), (c))
+#define SZG_CONTRACT SZG_CONTRACT_NONE
 #endif
+#include "szg/contraction.h"
 
 // GLSL built-ins: by default the pinned fp32 algorithms of szg/fpmath.h (so that oracle
 // and GPU kernels are reproducible bit for bit); with -DSZG_ORACLE_LIBM the correctly
@@ -116,7 +119,7 @@ struct vec4
 inline vec2 operator+(vec2 a, vec2 b) { return {a.x + b.x, a.y + b.y}; }
 inline vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
 inline vec2 operator*(vec2 a, float s) { return {a.x * s, a.y * s}; }
-inline float dot(vec2 a, vec2 b) { return SZG_FMA(a.y, b.y, a.x * b.x); } // OpDot: contraction rule, file header
+inline float dot(vec2 a, vec2 b) { return SZG_CON(SZG_C_DOT, a.y, b.y, a.x * b.x); } // OpDot: contraction rule, file header
 
 inline vec3 operator+(vec3 a, vec3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
 inline vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -138,12 +141,25 @@ inline vec3& operator*=(vec3& a, vec3 b)
     return a;
 }
 
-inline float dot(vec3 a, vec3 b) { return SZG_FMA(a.z, b.z, SZG_FMA(a.y, b.y, a.x * b.x)); } // OpDot
+inline float dot(vec3 a, vec3 b) { return SZG_CON(SZG_C_DOT, a.z, b.z, SZG_CON(SZG_C_DOT, a.y, b.y, a.x * b.x)); } // OpDot, shading geometry
+// OpDot written in common.glinl (atmosphere geometry: SZG_C_ATMODOT) and in transmittance_LUT.comp's loop (SZG_C_TMAIN)
+inline float dotA(vec3 a, vec3 b) { return SZG_CON(SZG_C_ATMODOT, a.z, b.z, SZG_CON(SZG_C_ATMODOT, a.y, b.y, a.x * b.x)); }
+inline float dotP(vec3 a, vec3 b) { return SZG_CON(SZG_C_PBRDOT, a.z, b.z, SZG_CON(SZG_C_PBRDOT, a.y, b.y, a.x * b.x)); } // pbrFunctions.glinl
+inline float dotL(vec3 a, vec3 b) { return SZG_CON(SZG_C_LDOT, a.z, b.z, SZG_CON(SZG_C_LDOT, a.y, b.y, a.x * b.x)); }   // lights.comp
+inline float dotL(vec2 a, vec2 b) { return SZG_CON(SZG_C_LDOT, a.y, b.y, a.x * b.x); }
+inline float dotT(vec3 a, vec3 b) { return SZG_CON(SZG_C_TMAIN, a.z, b.z, SZG_CON(SZG_C_TMAIN, a.y, b.y, a.x * b.x)); }
 inline float length(vec3 a) { return sqrtf(dot(a, a)); }
 inline float length(vec2 a) { return sqrtf(dot(a, a)); }
 inline float distance(vec3 a, vec3 b) { return length(a - b); }
 inline float distance(vec2 a, vec2 b) { return length(a - b); }
 inline float inversesqrt(float x) { return 1.0f / sqrtf(x); }
+inline float lengthA(vec3 a) { return sqrtf(dotA(a, a)); }
+inline float lengthT(vec3 a) { return sqrtf(dotT(a, a)); }
+inline vec3 normalizeA(vec3 v) { return v * inversesqrt(dotA(v, v)); }
+inline vec3 normalizeP(vec3 v) { return v * inversesqrt(dotP(v, v)); }
+inline vec3 normalizeL(vec3 v) { return v * inversesqrt(dotL(v, v)); }
+inline float distanceL(vec3 a, vec3 b) { return sqrtf(dotL(a - b, a - b)); }
+inline float distanceL(vec2 a, vec2 b) { return sqrtf(dotL(a - b, a - b)); }
 // normalize(v) = v * inversesqrt(dot(v, v))
 inline vec3 normalize(vec3 v) { return v * inversesqrt(dot(v, v)); }
 inline vec2 normalize(vec2 v) { return v * inversesqrt(dot(v, v)); }
@@ -152,13 +168,14 @@ inline vec3 clamp(vec3 v, float lo, float hi) { return {clampf(v.x, lo, hi), cla
 // mix(a, b, w) = a*(1-w) + b*w
 inline vec3 mix(vec3 a, vec3 b, vec3 w)
 {
-    return {SZG_FMA(b.x, w.x, a.x * (1.0f - w.x)), SZG_FMA(b.y, w.y, a.y * (1.0f - w.y)), SZG_FMA(b.z, w.z, a.z * (1.0f - w.z))};
+    return {SZG_CON(SZG_C_MIX, b.x, w.x, a.x * (1.0f - w.x)), SZG_CON(SZG_C_MIX, b.y, w.y, a.y * (1.0f - w.y)),
+            SZG_CON(SZG_C_MIX, b.z, w.z, a.z * (1.0f - w.z))};
 }
 inline vec3 mix(vec3 a, vec3 b, float w) { return mix(a, b, vec3(w)); }
 // contracted forms of  a * s + c,  a * b + c  and  c - t * d  (one rounding per component)
-inline vec3 fma3(vec3 a, float s, vec3 c) { return {SZG_FMA(a.x, s, c.x), SZG_FMA(a.y, s, c.y), SZG_FMA(a.z, s, c.z)}; }
-inline vec3 fma3(vec3 a, vec3 b, vec3 c) { return {SZG_FMA(a.x, b.x, c.x), SZG_FMA(a.y, b.y, c.y), SZG_FMA(a.z, b.z, c.z)}; }
-inline vec3 fnma(float t, vec3 d, vec3 c) { return {SZG_FMA(-t, d.x, c.x), SZG_FMA(-t, d.y, c.y), SZG_FMA(-t, d.z, c.z)}; }
+inline vec3 fma3(vec3 a, float s, vec3 c) { return {SZG_CON(SZG_C_ACCUM, a.x, s, c.x), SZG_CON(SZG_C_ACCUM, a.y, s, c.y), SZG_CON(SZG_C_ACCUM, a.z, s, c.z)}; }
+inline vec3 fma3(vec3 a, vec3 b, vec3 c) { return {SZG_CON(SZG_C_ACCUM, a.x, b.x, c.x), SZG_CON(SZG_C_ACCUM, a.y, b.y, c.y), SZG_CON(SZG_C_ACCUM, a.z, b.z, c.z)}; }
+inline vec3 fnma(float t, vec3 d, vec3 c) { return {SZG_CON(SZG_C_POINT, -t, d.x, c.x), SZG_CON(SZG_C_POINT, -t, d.y, c.y), SZG_CON(SZG_C_POINT, -t, d.z, c.z)}; }
 inline float smoothstep(float e0, float e1, float x)
 {
     float const t = clampf((x - e0) / (e1 - e0), 0.0f, 1.0f);
@@ -181,10 +198,10 @@ inline mat4 load(const szg_mat4& s)
 inline vec4 operator*(const mat4& a, vec4 v)
 {
     vec4 r;
-    r.x = SZG_FMA(a.m[12], v.w, SZG_FMA(a.m[8], v.z, SZG_FMA(a.m[4], v.y, a.m[0] * v.x)));
-    r.y = SZG_FMA(a.m[13], v.w, SZG_FMA(a.m[9], v.z, SZG_FMA(a.m[5], v.y, a.m[1] * v.x)));
-    r.z = SZG_FMA(a.m[14], v.w, SZG_FMA(a.m[10], v.z, SZG_FMA(a.m[6], v.y, a.m[2] * v.x)));
-    r.w = SZG_FMA(a.m[15], v.w, SZG_FMA(a.m[11], v.z, SZG_FMA(a.m[7], v.y, a.m[3] * v.x)));
+    r.x = SZG_CON(SZG_C_MATVEC, a.m[12], v.w, SZG_CON(SZG_C_MATVEC, a.m[8], v.z, SZG_CON(SZG_C_MATVEC, a.m[4], v.y, a.m[0] * v.x)));
+    r.y = SZG_CON(SZG_C_MATVEC, a.m[13], v.w, SZG_CON(SZG_C_MATVEC, a.m[9], v.z, SZG_CON(SZG_C_MATVEC, a.m[5], v.y, a.m[1] * v.x)));
+    r.z = SZG_CON(SZG_C_MATVEC, a.m[14], v.w, SZG_CON(SZG_C_MATVEC, a.m[10], v.z, SZG_CON(SZG_C_MATVEC, a.m[6], v.y, a.m[2] * v.x)));
+    r.w = SZG_CON(SZG_C_MATVEC, a.m[15], v.w, SZG_CON(SZG_C_MATVEC, a.m[11], v.z, SZG_CON(SZG_C_MATVEC, a.m[7], v.y, a.m[3] * v.x)));
     return r;
 }
 // glm's mat4 * mat4 as HOST code evaluates it: one rounding per operation (for matrices the reference computes on the CPU)
@@ -360,8 +377,8 @@ inline float sample_depth_border(const Image& im, vec2 uv)
 // texture() LINEAR / CLAMP_TO_EDGE, no mips, fp32 weights (skyview.cpp:199-207, :339-346)
 inline vec3 sample_linear_rgb(const Image& im, vec2 st)
 {
-    float const u = SZG_FMA(st.x, (float)im.width, -0.5f);
-    float const v = SZG_FMA(st.y, (float)im.height, -0.5f);
+    float const u = SZG_CON(SZG_C_TEXCOORD, st.x, (float)im.width, -0.5f);
+    float const v = SZG_CON(SZG_C_TEXCOORD, st.y, (float)im.height, -0.5f);
     float const fu = floorf(u);
     float const fv = floorf(v);
     float const a = u - fu;
@@ -382,9 +399,9 @@ inline vec3 sample_linear_rgb(const Image& im, vec2 st)
     float const w01 = (1.0f - a) * b;
     float const w11 = a * b;
     vec3 r;
-    r.x = SZG_FMA(w11, t11.x, SZG_FMA(w01, t01.x, SZG_FMA(w10, t10.x, w00 * t00.x)));
-    r.y = SZG_FMA(w11, t11.y, SZG_FMA(w01, t01.y, SZG_FMA(w10, t10.y, w00 * t00.y)));
-    r.z = SZG_FMA(w11, t11.z, SZG_FMA(w01, t01.z, SZG_FMA(w10, t10.z, w00 * t00.z)));
+    r.x = SZG_CON(SZG_C_BILINEAR, w11, t11.x, SZG_CON(SZG_C_BILINEAR, w01, t01.x, SZG_CON(SZG_C_BILINEAR, w10, t10.x, w00 * t00.x)));
+    r.y = SZG_CON(SZG_C_BILINEAR, w11, t11.y, SZG_CON(SZG_C_BILINEAR, w01, t01.y, SZG_CON(SZG_C_BILINEAR, w10, t10.y, w00 * t00.y)));
+    r.z = SZG_CON(SZG_C_BILINEAR, w11, t11.z, SZG_CON(SZG_C_BILINEAR, w01, t01.z, SZG_CON(SZG_C_BILINEAR, w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -445,7 +462,7 @@ inline float safeSqrt(float value) { return sqrtf(fmaxf(value, 0.0f)); }
 // common.glinl:29-32
 inline float textureCoordFromUnitRange(float value, int dimension)
 {
-    return SZG_FMA(value, 1.0f - 1.0f / (float)dimension, 0.5f / (float)dimension);
+    return SZG_CON(SZG_C_LUTMAP, value, 1.0f - 1.0f / (float)dimension, 0.5f / (float)dimension);
 }
 // common.glinl:33-36
 inline float unitRangeFromTextureCoord(float texCoord, int dimension)
@@ -460,7 +477,7 @@ vec2 transmittanceLUT_RMu_to_UV(const Atmosphere& atmosphere, const Transmittanc
     float const planetRadiusMmSquared = atmosphere.planetRadiusMm * atmosphere.planetRadiusMm;
     float const H = safeSqrt(atmospherRadiusMmSquared - planetRadiusMmSquared);
     float const rho = safeSqrt(radius * radius - planetRadiusMmSquared);
-    float const d = fmaxf(SZG_FMA(-radius, mu, safeSqrt(SZG_FMA(radius * radius, SZG_FMA(mu, mu, -1.0f), atmospherRadiusMmSquared))), 0.0f);
+    float const d = fmaxf(SZG_CON(SZG_C_LUTDIST, -radius, mu, safeSqrt(SZG_CON(SZG_C_LUTDIST, radius * radius, SZG_CON(SZG_C_LUTDIST, mu, mu, -1.0f), atmospherRadiusMmSquared))), 0.0f);
     float const d_min = atmosphere.atmosphereRadiusMm - radius;
     float const d_max = rho + H;
     float const x_mu = (d - d_min) / (d_max - d_min);
@@ -492,8 +509,8 @@ vec2 transmittanceLUT_UV_to_RMu(const Atmosphere& atmosphere, int lutWidth, int 
 // common.glinl:104-112
 vec3 sampleTransmittanceLUT_Ray(const TransmittanceLUT& LUT, const Atmosphere& atmosphere, vec3 position, vec3 direction)
 {
-    float const radius = length(position);
-    float const mu = (dot(position, direction) / (length(position) * length(direction)));
+    float const radius = lengthA(position);
+    float const mu = (dotA(position, direction) / (lengthA(position) * lengthA(direction)));
     vec2 const uv = transmittanceLUT_RMu_to_UV(atmosphere, LUT, radius, mu);
     return sample_linear_rgb(LUT.image, uv);
 }
@@ -502,8 +519,8 @@ vec3 sampleTransmittanceLUT_Ray(const TransmittanceLUT& LUT, const Atmosphere& a
 vec3 sampleTransmittanceLUT_Segment(const TransmittanceLUT& LUT, const Atmosphere& atmosphere, vec3 from, vec3 to)
 {
     vec3 transmittance;
-    vec3 const direction = normalize(to - from);
-    if (dot(from, direction) < 0.0f)
+    vec3 const direction = normalizeA(to - from);
+    if (dotA(from, direction) < 0.0f)
     {
         transmittance = sampleTransmittanceLUT_Ray(LUT, atmosphere, to, -direction) /
                         sampleTransmittanceLUT_Ray(LUT, atmosphere, from, -direction);
@@ -580,10 +597,10 @@ bool raySphereIntersection(vec3 rayOrigin, vec3 rayDirectionNormalized, float ra
 {
     vec3 const f = rayOrigin;
     vec3 const d = rayDirectionNormalized;
-    float const b = -1.0f * dot(f, d);
+    float const b = -1.0f * dotA(f, d);
     vec3 const centerToIntersectionChord = f + b * d;
-    float const discriminant = radius * radius - dot(centerToIntersectionChord, centerToIntersectionChord);
-    float const c = dot(f, f) - radius * radius;
+    float const discriminant = radius * radius - dotA(centerToIntersectionChord, centerToIntersectionChord);
+    float const c = dotA(f, f) - radius * radius;
     if (discriminant < 0.0f)
     {
         return false;
@@ -663,9 +680,9 @@ RaymarchStep stepRadiusMu(RaymarchStep start, float stepDistance)
         safeSqrt(start.mu_sun * start.mu - safeSqrt((1.0f - start.mu_sun * start.mu_sun) * (1.0f - start.mu * start.mu)));
     RaymarchStep result;
     result.radius =
-        safeSqrt(SZG_FMA(2.0f * start.radius * start.mu, stepDistance, stepDistance * stepDistance) + start.radius * start.radius);
+        safeSqrt(SZG_CON(SZG_C_STEP, 2.0f * start.radius * start.mu, stepDistance, stepDistance * stepDistance) + start.radius * start.radius);
     result.mu = (start.radius * start.mu + stepDistance) / result.radius;
-    result.mu_sun = SZG_FMA(stepDistance, mu_sunAndStepDirection, start.radius * start.mu_sun) / result.radius;
+    result.mu_sun = SZG_CON(SZG_C_STEP, stepDistance, mu_sunAndStepDirection, start.radius * start.mu_sun) / result.radius;
     return result;
 }
 
@@ -696,11 +713,11 @@ vec3 sampleTransmittanceLUT_RayMarchStep(const Atmosphere& atmosphere, const Tra
 vec3 computeLuminanceScatteringIntegral(const Atmosphere& atmosphere, const TransmittanceLUT& transmittanceLUT, vec3 origin,
                                         vec3 direction, float sampleDistance)
 {
-    vec3 const scatteringDir = -normalize(direction);
-    float const radius = length(origin);
-    float const mu = dot(origin, direction) / (length(origin) * length(direction));
+    vec3 const scatteringDir = -normalizeA(direction);
+    float const radius = lengthA(origin);
+    float const mu = dotA(origin, direction) / (lengthA(origin) * lengthA(direction));
     float const mu_sun =
-        dot(origin, -atmosphere.incidentDirectionSun) / (length(origin) * length(atmosphere.incidentDirectionSun));
+        dotA(origin, -atmosphere.incidentDirectionSun) / (lengthA(origin) * lengthA(atmosphere.incidentDirectionSun));
     RaymarchStep const originStep{radius, mu, mu_sun};
 
     vec3 luminance = vec3(0.0f);
@@ -712,13 +729,13 @@ vec3 computeLuminanceScatteringIntegral(const Atmosphere& atmosphere, const Tran
         vec3 const end = fnma(((float)(i + 1) * dSampleDistance), scatteringDir, origin);
 
         RaymarchStep const sampleStep = stepRadiusMu(originStep, t);
-        float const altitude = length(begin) - atmosphere.planetRadiusMm;
+        float const altitude = lengthA(begin) - atmosphere.planetRadiusMm;
         vec3 const transmittanceToSun =
             sampleTransmittanceLUT_Sun(transmittanceLUT, atmosphere, sampleStep.radius, sampleStep.mu_sun);
         ExtinctionSample const extinctionSample = sampleExtinction(atmosphere, altitude);
 
         vec3 const transmittanceToBegin = sampleTransmittanceLUT_RayMarchStep(atmosphere, transmittanceLUT, originStep, t);
-        float const incidentCosine = dot(atmosphere.incidentDirectionSun, scatteringDir);
+        float const incidentCosine = dotA(atmosphere.incidentDirectionSun, scatteringDir);
         vec3 const phaseTimesScattering = fma3(extinctionSample.scatteringMie, phaseMie(incidentCosine, 0.8f),
                                                extinctionSample.scatteringRayleigh * phaseRayleigh(incidentCosine));
         vec3 const shadowing = transmittanceToSun;
@@ -786,7 +803,7 @@ vec4 transmittance_texel(const Atmosphere& atmosphere, int W, int H, int tx, int
     {
         float const t = distanceThroughAtmosphere * ((float)i + 0.5f) / (float)SAMPLE_COUNT;
         vec3 const position = origin + t * direction;
-        float const altitude = length(position) - atmosphere.planetRadiusMm;
+        float const altitude = lengthT(position) - atmosphere.planetRadiusMm;
         ExtinctionSample const extinctionSample = sampleExtinction(atmosphere, altitude);
         transmittance *= exp3(-fabsf(dt) * extinctionSample.extinction);
     }
@@ -898,8 +915,8 @@ PBRTexel convertPBRProperties(const GBufferTexel& gbuffer)
 // pbrFunctions.glinl:22-32
 vec3 computeFresnel(const PBRTexel& material, vec3 lightOutgoing, vec3 viewOutgoing)
 {
-    vec3 const halfwayDirection = normalize(lightOutgoing + viewOutgoing);
-    float const p = GL_POW(1.0f - clampf(dot(halfwayDirection, lightOutgoing), 0.0f, 1.0f), 5.0f);
+    vec3 const halfwayDirection = normalizeP(lightOutgoing + viewOutgoing);
+    float const p = GL_POW(1.0f - clampf(dotP(halfwayDirection, lightOutgoing), 0.0f, 1.0f), 5.0f);
     return material.normalReflectance + (vec3(1.0f) - material.normalReflectance) * p;
 }
 // pbrFunctions.glinl:34-39
@@ -907,9 +924,9 @@ vec3 diffuseBRDF(const PBRTexel& material, vec3) { return material.subscattering
 // pbrFunctions.glinl:41-52
 vec3 specularBRDF(const PBRTexel& material, vec3 lightOutgoing, vec3 viewOutgoing)
 {
-    vec3 const halfwayDirection = normalize(lightOutgoing + viewOutgoing);
+    vec3 const halfwayDirection = normalizeP(lightOutgoing + viewOutgoing);
     float const specularPower = material.specularPower;
-    float const microfacetDistribution = GL_POW(clampf(dot(halfwayDirection, material.normal), 0.0f, 1.0f), specularPower);
+    float const microfacetDistribution = GL_POW(clampf(dotP(halfwayDirection, material.normal), 0.0f, 1.0f), specularPower);
     float const normalizationTerm = (specularPower + 2.0f) / 8.0f;
     return vec3(normalizationTerm * microfacetDistribution);
 }
@@ -987,7 +1004,7 @@ struct IncomingLight
 // lights.comp:65-71
 IncomingLight computeIncomingLight(const szg_directional_light_packed& light, const ShadowFrame& shadow, const szg_image* map)
 {
-    vec3 const lightDirectionUnit = normalize(-v3(light.forward));
+    vec3 const lightDirectionUnit = normalizeL(-v3(light.forward));
     vec3 const lightSpectralFactor = v3(light.color) * light.strength * sampleShadowMap(map, shadow);
     return {lightDirectionUnit, lightSpectralFactor};
 }
@@ -996,10 +1013,10 @@ IncomingLight computeIncomingLight(const szg_directional_light_packed& light, co
 IncomingLight computeIncomingLight(const szg_spot_light_packed& light, vec3 worldPosition, const ShadowFrame& shadow,
                                    const szg_image* map)
 {
-    vec3 const lightDirectionUnit = normalize(-v3(light.forward));
-    float const lightNormalizedDistance = distance(v3(light.position), worldPosition) / light.falloffDistance;
+    vec3 const lightDirectionUnit = normalizeL(-v3(light.forward));
+    float const lightNormalizedDistance = distanceL(v3(light.position), worldPosition) / light.falloffDistance;
     float const lightFalloff = light.falloffFactor * lightNormalizedDistance * lightNormalizedDistance;
-    float const distanceUV = clampf(distance(vec2{shadow.coord.x, shadow.coord.y}, vec2{0.5f, 0.5f}) / 0.5f, 0.0f, 1.0f);
+    float const distanceUV = clampf(distanceL(vec2{shadow.coord.x, shadow.coord.y}, vec2{0.5f, 0.5f}) / 0.5f, 0.0f, 1.0f);
     float const edgeSoftening = 1.0f - distanceUV * distanceUV;
     vec3 const lightSpectralFactor =
         v3(light.color) * light.strength / lightFalloff * edgeSoftening * sampleShadowMap(map, shadow);
@@ -1014,7 +1031,7 @@ vec3 computeLightContribution(const IncomingLight& light, const PBRTexel& materi
     vec3 const specularContribution = specularBRDF(material, lightDirection, viewDirection);
     vec3 const fresnel = computeFresnel(material, lightDirection, viewDirection);
     return material.occlusion * mix(diffuseContribution, specularContribution, fresnel) * light.lightSpectralFactor *
-           clampf(dot(material.normal, lightDirection), 0.0f, 1.0f);
+           clampf(dotL(material.normal, lightDirection), 0.0f, 1.0f);
 }
 
 // ----------------------------------------------------------------------------
@@ -1356,7 +1373,7 @@ void oracle_lights(const szg_scene_texture* scene, szg_rect drawRect, const szg_
                     continue;
                 }
                 PBRTexel const material = convertPBRProperties(gbufferTexel);
-                vec3 const viewDirection = normalize(v3(camera.position) - material.position);
+                vec3 const viewDirection = normalizeL(v3(camera.position) - material.position); // lights.comp:135
                 vec3 lightContribution = vec3(0.0f);
                 uint32_t shadowMapIndex = directionalLightSkipCount;
                 for (int i = (int)directionalLightSkipCount; i < (int)directionalLightCount; i++)

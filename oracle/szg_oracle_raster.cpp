@@ -27,10 +27,9 @@
 // i.e. executes the shaders' SPIR-V literally (libszg_oracle_literal.so; tests/test_spirv_pin.py compares that build, bit for
 // bit, with an interpreter run over the reference's committed .spv). The default build fuses.
 #ifdef SZG_ORACLE_LITERAL
-#define SZG_FMA(a, b, c) ((a) * (b) + (c))
-#else
-#define SZG_FMA(a, b, c) fmaf((a), (b), (c))
+#define SZG_CONTRACT SZG_CONTRACT_NONE
 #endif
+#include "szg/contraction.h"
 
 extern "C" uint16_t oracle_float_to_half(float f);
 
@@ -59,7 +58,7 @@ inline vec3 operator-(vec3 a, vec3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}
 inline vec3 operator-(vec3 a) { return {-a.x, -a.y, -a.z}; }
 inline vec3 operator*(vec3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 inline vec2 operator-(vec2 a, vec2 b) { return {a.x - b.x, a.y - b.y}; }
-inline float dot(vec3 a, vec3 b) { return SZG_FMA(a.z, b.z, SZG_FMA(a.y, b.y, a.x * b.x)); } // OpDot (szg_oracle.cpp header)
+inline float dot(vec3 a, vec3 b) { return SZG_CON(SZG_C_DOT, a.z, b.z, SZG_CON(SZG_C_DOT, a.y, b.y, a.x * b.x)); } // OpDot (szg_oracle.cpp header)
 inline vec3 cross(vec3 a, vec3 b) { return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
 inline float inversesqrt(float x) { return 1.0f / sqrtf(x); }
 inline vec3 normalize(vec3 v) { return v * inversesqrt(dot(v, v)); }
@@ -77,10 +76,10 @@ inline mat4 load(const szg_mat4& s)
 inline vec4 operator*(const mat4& a, vec4 v)
 {
     vec4 r;
-    r.x = SZG_FMA(a.m[12], v.w, SZG_FMA(a.m[8], v.z, SZG_FMA(a.m[4], v.y, a.m[0] * v.x)));
-    r.y = SZG_FMA(a.m[13], v.w, SZG_FMA(a.m[9], v.z, SZG_FMA(a.m[5], v.y, a.m[1] * v.x)));
-    r.z = SZG_FMA(a.m[14], v.w, SZG_FMA(a.m[10], v.z, SZG_FMA(a.m[6], v.y, a.m[2] * v.x)));
-    r.w = SZG_FMA(a.m[15], v.w, SZG_FMA(a.m[11], v.z, SZG_FMA(a.m[7], v.y, a.m[3] * v.x)));
+    r.x = SZG_CON(SZG_C_MATVEC, a.m[12], v.w, SZG_CON(SZG_C_MATVEC, a.m[8], v.z, SZG_CON(SZG_C_MATVEC, a.m[4], v.y, a.m[0] * v.x)));
+    r.y = SZG_CON(SZG_C_MATVEC, a.m[13], v.w, SZG_CON(SZG_C_MATVEC, a.m[9], v.z, SZG_CON(SZG_C_MATVEC, a.m[5], v.y, a.m[1] * v.x)));
+    r.z = SZG_CON(SZG_C_MATVEC, a.m[14], v.w, SZG_CON(SZG_C_MATVEC, a.m[10], v.z, SZG_CON(SZG_C_MATVEC, a.m[6], v.y, a.m[2] * v.x)));
+    r.w = SZG_CON(SZG_C_MATVEC, a.m[15], v.w, SZG_CON(SZG_C_MATVEC, a.m[11], v.z, SZG_CON(SZG_C_MATVEC, a.m[7], v.y, a.m[3] * v.x)));
     return r;
 }
 inline mat4 operator*(const mat4& a, const mat4& b)

@@ -248,7 +248,7 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
             r.shadowRows[row * 4 + col] = shadowMatrix.m[col * 4 + row];
         }
     }
-    V3 const dirUnit = normalize(-forward);
+    V3 const dirUnit = normalizeL(-forward);
     r.dir[0] = dirUnit.x;
     r.dir[1] = dirUnit.y;
     r.dir[2] = dirUnit.z;
@@ -329,7 +329,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     bool const isSpot = L.isSpot != 0u;
     V3 const lightDir = mk3(L.dir[0], L.dir[1], L.dir[2]);
     V3 const toLight = mk3(L.position[0], L.position[1], L.position[2]) - m.position;
-    float const d2 = dot(toLight, toLight);
+    float const d2 = dotL(toLight, toLight);
     // The surface faces away from the light: clamp(dot(N, L), 0, 1) = 0 (also for a NaN, fmax(NaN, 0) = 0) is the last factor
     // of ((occlusion * brdf) * spectral) * clamp(N.L) (lights.comp:106-107), so the term is +-0 - and sum + (+-0) == sum, the sum
     // being never -0 - provided the other factors are finite numbers whose product does not overflow:
@@ -340,13 +340,13 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     //   tested as falloffBound * d^2 >= 2^-28, the same quantity up to rounding, with a factor of 4 to spare (an infinite
     //   falloff gives spectral = 0).
     // Then nothing of this light needs evaluating for the pixel: a quarter of the lit pixel-light pairs of the bench scenes.
-    float const ndl = dot(m.normal, lightDir);
+    float const ndl = dotL(m.normal, lightDir);
     if (backCull && cullable && isSpot && L.leanOK != 0u && !(ndl > 0.0f) && L.falloffBound * d2 >= 0x1p-28f)
     {
         return splat(0.0f);
     }
     V3 const hs = lightDir + viewDirection;
-    float const hd = dot(hs, hs);
+    float const hd = dotP(hs, hs);
     // Operand ranges of the lean ops used below: w of the projected position, squared distance to the light
     // (=> lightFalloff = factor * (dist / falloffDistance)^2 with the per-light constants checked by k_light_prep),
     // the half-vector length, and the position magnitude. One lane outside sends the wave down the generic path.
@@ -354,7 +354,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     // (numerators too: the one-correction division returns NaN for an infinite numerator where the quotient is inf — a
     // projection with entries near FLT_MAX — and is not verified for denormal ones)
     float const cz = (L.map != nullptr)
-                         ? SZG_CFMA(R[10], m.position.z, SZG_CFMA(R[9], m.position.y, R[8] * m.position.x)) + R[11]
+                         ? SZG_CON(SZG_C_MATVEC, R[10], m.position.z, SZG_CON(SZG_C_MATVEC, R[9], m.position.y, R[8] * m.position.x)) + R[11]
                          : 0.0f;
     bool const lean = waveAll(L.leanOK != 0u && positionModerate && inRange(fabsf(cw), lo, hi) && inRange(d2, lo, hi) &&
                             inRange(hd, 0x1p-40f, 8.0f) && leanNumerator(cx) && leanNumerator(cy) && leanNumerator(cz));
@@ -370,7 +370,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
         // exactly 0 iff sqrt(q) * 2 >= 1 iff q >= 0.25 (sqrt is monotonic, sqrt(0.25) = 0.5 exactly), so the
         // cull needs no square root. x / 0.5 == x * 2 exactly.
         float const ddx = sx - 0.5f, ddy = sy - 0.5f;
-        float const q = SZG_CFMA(ddy, ddy, ddx * ddx); // dot(d, d) of distance()
+        float const q = SZG_CON(SZG_C_LDOT, ddy, ddy, ddx * ddx); // dot(d, d) of distance()
         if (q >= 0.25f && cullable)
         {
             return splat(0.0f);
@@ -386,8 +386,8 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     {
         float const sz = divU(lean, cz, cw, ycw);
         // projectedNormal = shadowMatrix * vec4(normal, 0)
-        float const nx = SZG_CFMA(R[3], 0.0f, SZG_CFMA(R[2], m.normal.z, SZG_CFMA(R[1], m.normal.y, R[0] * m.normal.x)));
-        float const ny = SZG_CFMA(R[7], 0.0f, SZG_CFMA(R[6], m.normal.z, SZG_CFMA(R[5], m.normal.y, R[4] * m.normal.x)));
+        float const nx = SZG_CON(SZG_C_MATVEC, R[3], 0.0f, SZG_CON(SZG_C_MATVEC, R[2], m.normal.z, SZG_CON(SZG_C_MATVEC, R[1], m.normal.y, R[0] * m.normal.x)));
+        float const ny = SZG_CON(SZG_C_MATVEC, R[7], 0.0f, SZG_CON(SZG_C_MATVEC, R[6], m.normal.z, SZG_CON(SZG_C_MATVEC, R[5], m.normal.y, R[4] * m.normal.x)));
         float const fdx = sqrtf(1.0f - clampf(nx * nx, 0.0f, 1.0f));
         float const fdy = sqrtf(1.0f - clampf(ny * ny, 0.0f, 1.0f));
         shadow = sampleShadowMap(L.map, L.mapWidth, L.mapHeight, L.mapPitchFloats, mk3(sx, sy, sz), fdx, fdy);
@@ -410,8 +410,8 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     V3 const h = hs * hinv;
     // both pow() without their special-case selects when no lane of the wave has a zero / denormal / non-finite base or a
     // zero exponent (szg_device.hpp powLean: the same values)
-    float const baseSpecular = clampf(dot(h, m.normal), 0.0f, 1.0f);
-    float const baseFresnel = 1.0f - clampf(dot(h, lightDir), 0.0f, 1.0f);
+    float const baseSpecular = clampf(dotP(h, m.normal), 0.0f, 1.0f);
+    float const baseFresnel = 1.0f - clampf(dotP(h, lightDir), 0.0f, 1.0f);
     bool const powsLean = waveAll(powLeanOK(baseSpecular, m.specularPower) && powLeanOK(baseFresnel, 5.0f));
     float const microfacet = powsLean ? powLean(baseSpecular, m.specularPower) : szg_powf(baseSpecular, m.specularPower);
     V3 const specular = splat(m.normalization * microfacet);
@@ -445,9 +445,9 @@ SZG_DEV LightCull loadCull(const LightRec* __restrict__ L)
 SZG_DEV V3 projectRows(const LightCull& c, V3 p)
 {
     // (M * vec4(p, 1)).row as the oracle's operator* evaluates it: an fma chain over x, y, z, then + m3 * 1
-    float const cx = SZG_CFMA(c.rx[2], p.z, SZG_CFMA(c.rx[1], p.y, c.rx[0] * p.x)) + c.rx[3];
-    float const cy = SZG_CFMA(c.ry[2], p.z, SZG_CFMA(c.ry[1], p.y, c.ry[0] * p.x)) + c.ry[3];
-    float const cw = SZG_CFMA(c.rw[2], p.z, SZG_CFMA(c.rw[1], p.y, c.rw[0] * p.x)) + c.rw[3];
+    float const cx = SZG_CON(SZG_C_MATVEC, c.rx[2], p.z, SZG_CON(SZG_C_MATVEC, c.rx[1], p.y, c.rx[0] * p.x)) + c.rx[3];
+    float const cy = SZG_CON(SZG_C_MATVEC, c.ry[2], p.z, SZG_CON(SZG_C_MATVEC, c.ry[1], p.y, c.ry[0] * p.x)) + c.ry[3];
+    float const cw = SZG_CON(SZG_C_MATVEC, c.rw[2], p.z, SZG_CON(SZG_C_MATVEC, c.rw[1], p.y, c.rw[0] * p.x)) + c.rw[3];
     return V3{cx, cy, cw};
 }
 SZG_DEV bool surelyOutsideCone(V3 clip)
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug
         float4 const p4 = row_ptr<const float4>(g.position, y)[x];
         Material const m = convertPBR(V4{p4.x, p4.y, p4.z, p4.w}, normal, diffuse, specular, orm);
         const szg_camera_packed* cam = cameras + cameraIndex;
-        V3 const viewDirection = normalize(mk3(cam->position[0], cam->position[1], cam->position[2]) - m.position);
+        V3 const viewDirection = normalizeL(mk3(cam->position[0], cam->position[1], cam->position[2]) - m.position);
 
         float const hi = 0x1p30f;
         bool const positionModerate = fabsf(m.position.x) <= hi && fabsf(m.position.y) <= hi && fabsf(m.position.z) <= hi;

@@ -37,7 +37,7 @@ template <bool LEAN> SZG_DEV V3 transmittanceProduct(const Atm& a, V3 origin, V3
         int const i = k * T_LANES + sub;
         float const t = divRX<LEAN>(distance * ((float)i + 0.5f), 500.0f, rcp500);
         V3 const position = origin + t * direction;
-        float const altitude = sqrtPX<LEAN>(dot(position, position)) - a.planetRadius;
+        float const altitude = sqrtPX<LEAN>(dotT(position, position)) - a.planetRadius; // length(position), transmittance_LUT.comp:97
         Extinction const e = sampleExtinction<LEAN>(a, altitude);
         bool const valid = i < T_STEPS;
         float const fx = valid ? expX<LEAN>(ndt * e.extinction.x) : 1.0f;

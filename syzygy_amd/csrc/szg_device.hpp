@@ -44,24 +44,34 @@ SZG_DEV V3 operator/(V3 a, V3 b) { return V3{a.x / b.x, a.y / b.y, a.z / b.z}; }
 SZG_DEV V3 operator*(V3 a, float s) { return V3{a.x * s, a.y * s, a.z * s}; }
 SZG_DEV V3 operator*(float s, V3 a) { return V3{s * a.x, s * a.y, s * a.z}; }
 SZG_DEV V3 operator/(V3 a, float s) { return V3{a.x / s, a.y / s, a.z / s}; }
-// Contraction rule (oracle/szg_oracle.cpp header): dot, matrix * vector, mix, bilinear fetches, the LUT coordinate maps and
-// the march's geometry / accumulation use fused multiply-adds, explicitly and at the same places as the oracle; the
-// compiler itself contracts nothing (-ffp-contract=off). The rule is ONE switch, as in the oracle (SZG_FMA there):
-// -DSZG_LITERAL builds libszg_hip_literal.so, the same kernels with two roundings at those places, i.e. kernels that
-// execute the shaders' SPIR-V literally; tests/test_gpu_spirv_pin.py compares that build, bit for bit and on the GPU, with
-// the vectors an interpreter recorded from the reference's committed .spv (tests/golden/spirv_vectors.npz). The fused
-// multiply-adds INSIDE the exact operators below (rcpN, divR, sqrtN, exp / log polynomials) are not part of the rule: they
-// are how those operators reach their correctly rounded results, and stay.
+// Contraction rule (include/szg/contraction.h): a * b + c is fused only at a closed list of places, by site class, explicitly
+// and at the same places as the oracle; the compiler itself contracts nothing (-ffp-contract=off). -DSZG_LITERAL builds
+// libszg_hip_literal.so (SZG_CONTRACT = 0: two roundings everywhere), i.e. kernels that execute the shaders' SPIR-V
+// literally; tests/test_gpu_spirv_pin.py compares that build, bit for bit and on the GPU, with the vectors an interpreter
+// recorded from the reference's committed .spv (tests/golden/spirv_vectors.npz), and holds the product to 1e-4 / 1 LSB of
+// them. The fused multiply-adds INSIDE the exact operators below (rcpN, divR, sqrtN, exp / log polynomials) are not part of
+// the rule: they are how those operators reach their correctly rounded results, and stay.
 #ifdef SZG_LITERAL
-#define SZG_CFMA(a, b, c) ((a) * (b) + (c))
-#else
-#define SZG_CFMA(a, b, c) __builtin_fmaf((a), (b), (c))
+#define SZG_CONTRACT SZG_CONTRACT_NONE
 #endif
-SZG_DEV float dot(V3 a, V3 b) { return SZG_CFMA(a.z, b.z, SZG_CFMA(a.y, b.y, a.x * b.x)); }
-SZG_DEV float dot(V2 a, V2 b) { return SZG_CFMA(a.y, b.y, a.x * b.x); }
-SZG_DEV V3 fma3(V3 a, float s, V3 c) { return V3{SZG_CFMA(a.x, s, c.x), SZG_CFMA(a.y, s, c.y), SZG_CFMA(a.z, s, c.z)}; }
-SZG_DEV V3 fma3(V3 a, V3 b, V3 c) { return V3{SZG_CFMA(a.x, b.x, c.x), SZG_CFMA(a.y, b.y, c.y), SZG_CFMA(a.z, b.z, c.z)}; }
-SZG_DEV V3 fnma(float t, V3 d, V3 c) { return V3{SZG_CFMA(-t, d.x, c.x), SZG_CFMA(-t, d.y, c.y), SZG_CFMA(-t, d.z, c.z)}; }
+} // namespace szg
+#include "szg/contraction.h"
+namespace szg
+{
+// shading geometry (SZG_C_DOT) ...
+SZG_DEV float dot(V3 a, V3 b) { return SZG_CON(SZG_C_DOT, a.z, b.z, SZG_CON(SZG_C_DOT, a.y, b.y, a.x * b.x)); }
+SZG_DEV float dot(V2 a, V2 b) { return SZG_CON(SZG_C_DOT, a.y, b.y, a.x * b.x); }
+// ... and the atmosphere geometry of common.glinl (SZG_C_ATMODOT: raySphere, the LUT samplers, the march)
+SZG_DEV float dotA(V3 a, V3 b) { return SZG_CON(SZG_C_ATMODOT, a.z, b.z, SZG_CON(SZG_C_ATMODOT, a.y, b.y, a.x * b.x)); }
+// pbrFunctions.glinl (SZG_C_PBRDOT) and lights.comp (SZG_C_LDOT)
+SZG_DEV float dotP(V3 a, V3 b) { return SZG_CON(SZG_C_PBRDOT, a.z, b.z, SZG_CON(SZG_C_PBRDOT, a.y, b.y, a.x * b.x)); }
+SZG_DEV float dotL(V3 a, V3 b) { return SZG_CON(SZG_C_LDOT, a.z, b.z, SZG_CON(SZG_C_LDOT, a.y, b.y, a.x * b.x)); }
+// length(position) in the 500-step loop of transmittance_LUT.comp (SZG_C_TMAIN)
+SZG_DEV float dotT(V3 a, V3 b) { return SZG_CON(SZG_C_TMAIN, a.z, b.z, SZG_CON(SZG_C_TMAIN, a.y, b.y, a.x * b.x)); }
+// the march's accumulations (SZG_C_ACCUM) and sample points (SZG_C_POINT)
+SZG_DEV V3 fma3(V3 a, float s, V3 c) { return V3{SZG_CON(SZG_C_ACCUM, a.x, s, c.x), SZG_CON(SZG_C_ACCUM, a.y, s, c.y), SZG_CON(SZG_C_ACCUM, a.z, s, c.z)}; }
+SZG_DEV V3 fma3(V3 a, V3 b, V3 c) { return V3{SZG_CON(SZG_C_ACCUM, a.x, b.x, c.x), SZG_CON(SZG_C_ACCUM, a.y, b.y, c.y), SZG_CON(SZG_C_ACCUM, a.z, b.z, c.z)}; }
+SZG_DEV V3 fnma(float t, V3 d, V3 c) { return V3{SZG_CON(SZG_C_POINT, -t, d.x, c.x), SZG_CON(SZG_C_POINT, -t, d.y, c.y), SZG_CON(SZG_C_POINT, -t, d.z, c.z)}; }
 SZG_DEV float length(V3 a) { return sqrtf(dot(a, a)); }
 SZG_DEV V3 normalize(V3 v)
 {
@@ -73,12 +83,28 @@ SZG_DEV V2 normalize(V2 v)
     float const s = 1.0f / sqrtf(dot(v, v));
     return V2{v.x * s, v.y * s};
 }
+SZG_DEV V3 normalizeP(V3 v)
+{
+    float const s = 1.0f / sqrtf(dotP(v, v));
+    return v * s;
+}
+SZG_DEV V3 normalizeL(V3 v)
+{
+    float const s = 1.0f / sqrtf(dotL(v, v));
+    return v * s;
+}
+SZG_DEV float lengthA(V3 a) { return sqrtf(dotA(a, a)); }
+SZG_DEV V3 normalizeA(V3 v)
+{
+    float const s = 1.0f / sqrtf(dotA(v, v));
+    return v * s;
+}
 SZG_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 SZG_DEV V3 clamp01(V3 v) { return V3{clampf(v.x, 0.0f, 1.0f), clampf(v.y, 0.0f, 1.0f), clampf(v.z, 0.0f, 1.0f)}; }
 SZG_DEV V3 mix(V3 a, V3 b, V3 w)
 {
-    return V3{SZG_CFMA(b.x, w.x, a.x * (1.0f - w.x)), SZG_CFMA(b.y, w.y, a.y * (1.0f - w.y)),
-              SZG_CFMA(b.z, w.z, a.z * (1.0f - w.z))};
+    return V3{SZG_CON(SZG_C_MIX, b.x, w.x, a.x * (1.0f - w.x)), SZG_CON(SZG_C_MIX, b.y, w.y, a.y * (1.0f - w.y)),
+              SZG_CON(SZG_C_MIX, b.z, w.z, a.z * (1.0f - w.z))};
 }
 SZG_DEV float smoothstep(float e0, float e1, float x)
 {
@@ -229,10 +255,10 @@ struct M4
 SZG_DEV V4 mul(const M4& a, float x, float y, float z, float w)
 {
     V4 r;
-    r.x = SZG_CFMA(a.m[12], w, SZG_CFMA(a.m[8], z, SZG_CFMA(a.m[4], y, a.m[0] * x)));
-    r.y = SZG_CFMA(a.m[13], w, SZG_CFMA(a.m[9], z, SZG_CFMA(a.m[5], y, a.m[1] * x)));
-    r.z = SZG_CFMA(a.m[14], w, SZG_CFMA(a.m[10], z, SZG_CFMA(a.m[6], y, a.m[2] * x)));
-    r.w = SZG_CFMA(a.m[15], w, SZG_CFMA(a.m[11], z, SZG_CFMA(a.m[7], y, a.m[3] * x)));
+    r.x = SZG_CON(SZG_C_MATVEC, a.m[12], w, SZG_CON(SZG_C_MATVEC, a.m[8], z, SZG_CON(SZG_C_MATVEC, a.m[4], y, a.m[0] * x)));
+    r.y = SZG_CON(SZG_C_MATVEC, a.m[13], w, SZG_CON(SZG_C_MATVEC, a.m[9], z, SZG_CON(SZG_C_MATVEC, a.m[5], y, a.m[1] * x)));
+    r.z = SZG_CON(SZG_C_MATVEC, a.m[14], w, SZG_CON(SZG_C_MATVEC, a.m[10], z, SZG_CON(SZG_C_MATVEC, a.m[6], y, a.m[2] * x)));
+    r.w = SZG_CON(SZG_C_MATVEC, a.m[15], w, SZG_CON(SZG_C_MATVEC, a.m[11], z, SZG_CON(SZG_C_MATVEC, a.m[7], y, a.m[3] * x)));
     return r;
 }
 SZG_DEV M4 mul(const M4& a, const M4& b)
@@ -576,10 +602,10 @@ SZG_DEV Extinction extinctionFromDensities(const Atm& a, float altitude, float d
 // common.glinl:220-260
 SZG_DEV bool raySphere(V3 f, V3 d, float radius, float& t0, float& t1)
 {
-    float const b = -1.0f * dot(f, d);
+    float const b = -1.0f * dotA(f, d);
     V3 const chord = f + b * d;
-    float const discriminant = radius * radius - dot(chord, chord);
-    float const c = dot(f, f) - radius * radius;
+    float const discriminant = radius * radius - dotA(chord, chord);
+    float const c = dotA(f, f) - radius * radius;
     if (discriminant < 0.0f)
     {
         return false;
@@ -714,8 +740,8 @@ SZG_DEV TLut make_tlut(const float4* texels, int w, int h, const FramePrep& f)
 
 SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float fW, float fH, float s, float t)
 {
-    float const u = SZG_CFMA(s, fW, -0.5f);
-    float const v = SZG_CFMA(t, fH, -0.5f);
+    float const u = SZG_CON(SZG_C_TEXCOORD, s, fW, -0.5f);
+    float const v = SZG_CON(SZG_C_TEXCOORD, t, fH, -0.5f);
     float const fu = floorf(u);
     float const fv = floorf(v);
     float const a = u - fu;
@@ -735,9 +761,9 @@ SZG_DEV V3 bilinear_rgb(const float4* __restrict__ texels, int W, int H, float f
     float const w01 = (1.0f - a) * b;
     float const w11 = a * b;
     V3 r;
-    r.x = SZG_CFMA(w11, t11.x, SZG_CFMA(w01, t01.x, SZG_CFMA(w10, t10.x, w00 * t00.x)));
-    r.y = SZG_CFMA(w11, t11.y, SZG_CFMA(w01, t01.y, SZG_CFMA(w10, t10.y, w00 * t00.y)));
-    r.z = SZG_CFMA(w11, t11.z, SZG_CFMA(w01, t01.z, SZG_CFMA(w10, t10.z, w00 * t00.z)));
+    r.x = SZG_CON(SZG_C_BILINEAR, w11, t11.x, SZG_CON(SZG_C_BILINEAR, w01, t01.x, SZG_CON(SZG_C_BILINEAR, w10, t10.x, w00 * t00.x)));
+    r.y = SZG_CON(SZG_C_BILINEAR, w11, t11.y, SZG_CON(SZG_C_BILINEAR, w01, t01.y, SZG_CON(SZG_C_BILINEAR, w10, t10.y, w00 * t00.y)));
+    r.z = SZG_CON(SZG_C_BILINEAR, w11, t11.z, SZG_CON(SZG_C_BILINEAR, w01, t01.z, SZG_CON(SZG_C_BILINEAR, w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -769,8 +795,8 @@ template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const 
     p.denom = d_max - p.d_min;
     p.rcpDenom = LEAN ? rcpN(p.denom) : 0.0f;
     float const x_radius = divRX<LEAN>(rho, a.H, a.rcpH);
-    float const t = SZG_CFMA(x_radius, L.v_scale, L.v_bias);
-    float const v = SZG_CFMA(t, L.fheight, -0.5f);
+    float const t = SZG_CON(SZG_C_LUTMAP, x_radius, L.v_scale, L.v_bias);
+    float const v = SZG_CON(SZG_C_TEXCOORD, t, L.fheight, -0.5f);
     float const fv = floorf(v);
     p.b = v - fv;
     p.omb = 1.0f - p.b;
@@ -792,11 +818,11 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
     // where a march segment has length 0 (geometry nearer than 32 ulps of the planet radius, ~15 m: normalize(0) = NaN,
     // common.glinl:114-136), and max(NaN, 0) = 0 is what the reference then samples with (found by the 6 000-seed sweep of
     // round 2: a version without this clamp let the NaN through to the texel weights in 8 of 6 000 random frames).
-    float const disc = SZG_CFMA(p.r2, SZG_CFMA(mu, mu, -1.0f), a.Ra2);
-    float const d = fmaxf(SZG_CFMA(-p.r, mu, (LEAN && INNER) ? sqrtP(disc) : safeSqrtX<LEAN>(disc)), 0.0f);
+    float const disc = SZG_CON(SZG_C_LUTDIST, p.r2, SZG_CON(SZG_C_LUTDIST, mu, mu, -1.0f), a.Ra2);
+    float const d = fmaxf(SZG_CON(SZG_C_LUTDIST, -p.r, mu, (LEAN && INNER) ? sqrtP(disc) : safeSqrtX<LEAN>(disc)), 0.0f);
     float const x_mu = divRX<LEAN>(d - p.d_min, p.denom, p.rcpDenom);
-    float const s = SZG_CFMA(x_mu, L.u_scale, L.u_bias);
-    float const u = SZG_CFMA(s, L.fwidth, -0.5f);
+    float const s = SZG_CON(SZG_C_LUTMAP, x_mu, L.u_scale, L.u_bias);
+    float const u = SZG_CON(SZG_C_TEXCOORD, s, L.fwidth, -0.5f);
     float const fu = floorf(u);
     float const al = u - fu;
     float const wm1 = L.fwidth - 1.0f;
@@ -837,9 +863,9 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
     float const w01 = oma * p.b;
     float const w11 = al * p.b;
     V3 r;
-    r.x = SZG_CFMA(w11, t11.x, SZG_CFMA(w01, t01.x, SZG_CFMA(w10, t10.x, w00 * t00.x)));
-    r.y = SZG_CFMA(w11, t11.y, SZG_CFMA(w01, t01.y, SZG_CFMA(w10, t10.y, w00 * t00.y)));
-    r.z = SZG_CFMA(w11, t11.z, SZG_CFMA(w01, t01.z, SZG_CFMA(w10, t10.z, w00 * t00.z)));
+    r.x = SZG_CON(SZG_C_BILINEAR, w11, t11.x, SZG_CON(SZG_C_BILINEAR, w01, t01.x, SZG_CON(SZG_C_BILINEAR, w10, t10.x, w00 * t00.x)));
+    r.y = SZG_CON(SZG_C_BILINEAR, w11, t11.y, SZG_CON(SZG_C_BILINEAR, w01, t01.y, SZG_CON(SZG_C_BILINEAR, w10, t10.y, w00 * t00.y)));
+    r.z = SZG_CON(SZG_C_BILINEAR, w11, t11.z, SZG_CON(SZG_C_BILINEAR, w01, t01.z, SZG_CON(SZG_C_BILINEAR, w10, t10.z, w00 * t00.z)));
     return r;
 }
 
@@ -861,13 +887,13 @@ template <bool LEAN = false> SZG_DEV V3 sampleT_Ray(const TLut& L, const Atm& a,
 {
     if (LEAN)
     {
-        // length() = sqrt(dot) and the quotient, with the lean exact operators (same values)
-        float const radius = sqrtP(dot(position, position));
-        float const mu = divN0(dot(position, direction), radius * sqrtP(dot(direction, direction)));
+        // lengthA() = sqrt(dot) and the quotient, with the lean exact operators (same values)
+        float const radius = sqrtP(dotA(position, position));
+        float const mu = divN0(dotA(position, direction), radius * sqrtP(dotA(direction, direction)));
         return sampleT_RadiusMu<true>(L, a, radius, mu);
     }
-    float const radius = length(position);
-    float const mu = dot(position, direction) / (length(position) * length(direction));
+    float const radius = lengthA(position);
+    float const mu = dotA(position, direction) / (lengthA(position) * lengthA(direction));
     return sampleT_RadiusMu(L, a, radius, mu);
 }
 
@@ -901,19 +927,19 @@ template <bool LEAN = false> SZG_DEV V3 sampleT_Segment(const TLut& L, const Atm
     if (LEAN)
     {
         V3 const segment = to - from;
-        V3 const direction = segment * divN0(1.0f, sqrtP(dot(segment, segment))); // normalize()
-        float const lenFrom = sqrtP(dot(from, from));
-        float const lenTo = sqrtP(dot(to, to));
+        V3 const direction = segment * divN0(1.0f, sqrtP(dotA(segment, segment))); // normalizeA()
+        float const lenFrom = sqrtP(dotA(from, from));
+        float const lenTo = sqrtP(dotA(to, to));
         RadiusPart const pf = radiusPart<true>(L, a, lenFrom);
         RadiusPart const pt = radiusPart<true>(L, a, lenTo);
-        return segmentRatio<true>(L, a, pf, dot(from, direction), lenFrom, pt, dot(to, direction), lenTo, sqrtP(dot(direction, direction)));
+        return segmentRatio<true>(L, a, pf, dotA(from, direction), lenFrom, pt, dotA(to, direction), lenTo, sqrtP(dotA(direction, direction)));
     }
-    V3 const direction = normalize(to - from);
-    float const lenFrom = length(from);
-    float const lenTo = length(to);
+    V3 const direction = normalizeA(to - from);
+    float const lenFrom = lengthA(from);
+    float const lenTo = lengthA(to);
     RadiusPart const pf = radiusPart<false>(L, a, lenFrom);
     RadiusPart const pt = radiusPart<false>(L, a, lenTo);
-    return segmentRatio<false>(L, a, pf, dot(from, direction), lenFrom, pt, dot(to, direction), lenTo, length(direction));
+    return segmentRatio<false>(L, a, pf, dotA(from, direction), lenFrom, pt, dotA(to, direction), lenTo, lengthA(direction));
 }
 
 // common.glinl:263-279
@@ -962,7 +988,7 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
     // `end` of step i and `begin` of step i+1 are the same expression (common.glinl:386-387),
     // so its length and radius part are carried from one iteration to the next.
     V3 begin = fnma(0.0f * m.dS, m.scatteringDir, m.origin);
-    float lenBegin = sqrtPX<LEAN>(dot(begin, begin));
+    float lenBegin = sqrtPX<LEAN>(dotA(begin, begin));
     RadiusPart pBegin = radiusPart<LEAN>(L, a, lenBegin);
 #pragma unroll 1
     for (unsigned i = 0; i < 32u; i++)
@@ -970,16 +996,16 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
         float const fi = (float)i;
         float const t = fi * m.dS;
         V3 const end = fnma((float)(i + 1u) * m.dS, m.scatteringDir, m.origin);
-        float const lenEnd = sqrtPX<LEAN>(dot(end, end));
+        float const lenEnd = sqrtPX<LEAN>(dotA(end, end));
         RadiusPart const pEnd = radiusPart<LEAN>(L, a, lenEnd);
 
         // stepRadiusMu(originStep, t), common.glinl:329-331
         // (on a lean path this is a squared radius above the lean floor: neither the clamp to 0 nor sqrtN's guard is needed)
-        float const s_q = SZG_CFMA(m.two_r_mu, t, t * t) + m.r2;
+        float const s_q = SZG_CON(SZG_C_STEP, m.two_r_mu, t, t * t) + m.r2;
         float const s_radius = LEAN ? sqrtP(s_q) : safeSqrt(s_q);
         float const yS = LEAN ? rcpN(s_radius) : 0.0f;
         float const s_mu = divRX<LEAN>(m.r_mu + t, s_radius, yS);
-        float const s_musun = divRX<LEAN>(SZG_CFMA(t, m.mu_sunAndStep, m.r_musun), s_radius, yS);
+        float const s_musun = divRX<LEAN>(SZG_CON(SZG_C_STEP, t, m.mu_sunAndStep, m.r_musun), s_radius, yS);
         RadiusPart const pStep = radiusPart<LEAN>(L, a, s_radius);
 
         float const altitude = lenBegin - a.planetRadius;
@@ -1038,21 +1064,21 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
         V3 const phaseTimesScattering = fma3(ex.scatteringMie, m.pM, ex.scatteringRayleigh * m.pR);
 
         // sampleTransmittanceLUT_Segment(begin, end), common.glinl:114-136. The segment can be arbitrarily short
-        // (geometry close to the camera: end - begin may even be 0 and its normal NaN), so normalize() keeps the
+        // (geometry close to the camera: end - begin may even be 0 and its normal NaN), so normalizeA() keeps the
         // generic operators unless the squared length is comfortably normal for the whole wave.
         V3 const segment = end - begin;
-        float const segment2 = dot(segment, segment);
+        float const segment2 = dotA(segment, segment);
         V3 segDir;
         if (LEAN && waveAll(inRange(segment2, 0x1p-90f, 0x1p60f)))
         {
-            segDir = segment * divN0(1.0f, sqrtP(segment2)); // = segment * (1 / sqrt(dot)) of normalize()
+            segDir = segment * divN0(1.0f, sqrtP(segment2)); // = segment * (1 / sqrt(dot)) of normalizeA()
         }
         else
         {
-            segDir = normalize(segment);
+            segDir = normalizeA(segment);
         }
-        V3 const T_path = segmentRatio<LEAN, INNER>(L, a, pBegin, dot(begin, segDir), lenBegin, pEnd, dot(end, segDir), lenEnd,
-                                             sqrtPX<LEAN>(dot(segDir, segDir)));
+        V3 const T_path = segmentRatio<LEAN, INNER>(L, a, pBegin, dotA(begin, segDir), lenBegin, pEnd, dotA(end, segDir), lenEnd,
+                                             sqrtPX<LEAN>(dotA(segDir, segDir)));
         // 1 - T_path is 0 or a multiple of 2^-24; the extinction is in [2^-40, 2^52] when m.extLean
         V3 const oneMinusT = splat(1.0f) - T_path;
         V3 const integral = (LEAN && m.extLean) ? V3{divN0(oneMinusT.x, ex.extinction.x), divN0(oneMinusT.y, ex.extinction.y),
@@ -1073,8 +1099,8 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     m.origin = origin;
     // The per-ray setup with the lean exact operators (same values) when the whole wave's origins lie above the lean floor
     // and the direction and sun vectors have ordinary lengths; otherwise hipcc's generic sqrtf / division.
-    float const origin2 = dot(origin, origin), direction2 = dot(direction, direction);
-    float const sun2 = dot(a.incidentDirectionSun, a.incidentDirectionSun);
+    float const origin2 = dotA(origin, origin), direction2 = dotA(direction, direction);
+    float const sun2 = dotA(a.incidentDirectionSun, a.incidentDirectionSun);
     bool const setupLean = waveAll(a.lean && leanRadius2(a, origin2) && leanLength2(direction2) && leanLength2(sun2));
     float radius, mu, mu_sun;
     V3 const toSun = -a.incidentDirectionSun;
@@ -1083,18 +1109,18 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
         float const lenDirection = sqrtP(direction2);
         m.scatteringDir = -(direction * divN0(1.0f, lenDirection));
         radius = sqrtP(origin2);
-        mu = divN0(dot(origin, direction), radius * lenDirection);
-        mu_sun = divN0(dot(origin, toSun), radius * sqrtP(sun2));
+        mu = divN0(dotA(origin, direction), radius * lenDirection);
+        mu_sun = divN0(dotA(origin, toSun), radius * sqrtP(sun2));
     }
     else
     {
-        m.scatteringDir = -normalize(direction);
-        radius = length(origin);
-        mu = dot(origin, direction) / (length(origin) * length(direction));
-        mu_sun = dot(origin, toSun) / (length(origin) * length(a.incidentDirectionSun));
+        m.scatteringDir = -normalizeA(direction);
+        radius = lengthA(origin);
+        mu = dotA(origin, direction) / (lengthA(origin) * lengthA(direction));
+        mu_sun = dotA(origin, toSun) / (lengthA(origin) * lengthA(a.incidentDirectionSun));
     }
 
-    float const incidentCosine = dot(a.incidentDirectionSun, m.scatteringDir);
+    float const incidentCosine = dotA(a.incidentDirectionSun, m.scatteringDir);
     m.pR = phaseRayleigh(incidentCosine);
     m.pM = phaseMie(incidentCosine, 0.8f);
     m.sin_sunRadius = szg_sinf(a.sunAngularRadius);
@@ -1113,7 +1139,7 @@ SZG_DEV V3 scatteringIntegral(const TLut& L, const Atm& a, V3 origin, V3 directi
     // leanRay: every radius met along the path stays >= 0.9 Rp and of moderate magnitude, the path length is
     // moderate, and the smoothstep span 2 * sin_hz * sin(sunRadius) is a normal number. The closest approach of
     // the segment [0, L] to the planet centre is at t* = -r*mu when that lies inside the segment.
-    float const L2 = SZG_CFMA(m.two_r_mu, sampleDistance, sampleDistance * sampleDistance) + m.r2; // stepRadiusMu's form
+    float const L2 = SZG_CON(SZG_C_STEP, m.two_r_mu, sampleDistance, sampleDistance * sampleDistance) + m.r2; // stepRadiusMu's form
     float const tStar = -m.r_mu;
     float const rmin2 = (tStar > 0.0f && tStar < sampleDistance) ? m.r2 * (1.0f - mu * mu) : fminf(m.r2, L2);
     // ... and the two cosines are cosines: a sun (or view) vector of length 0 or inf makes mu_sun (mu) infinite or NaN, and
@@ -1195,11 +1221,11 @@ SZG_DEV Material convertPBR(V4 position, V4 normal, V4 diffuse, V4 specular, V4 
 template <bool LEAN = false> SZG_DEV V3 brdfMix(const Material& m, V3 lightDir, V3 viewDir)
 {
     V3 const hs = lightDir + viewDir;
-    float const hd = dot(hs, hs);
+    float const hd = dotP(hs, hs);
     V3 const h = hs * divX<LEAN>(1.0f, sqrtX<LEAN>(hd));
-    float const microfacet = szg_powf(clampf(dot(h, m.normal), 0.0f, 1.0f), m.specularPower);
+    float const microfacet = szg_powf(clampf(dotP(h, m.normal), 0.0f, 1.0f), m.specularPower);
     V3 const specular = splat(m.normalization * microfacet);
-    float const p = szg_powf(1.0f - clampf(dot(h, lightDir), 0.0f, 1.0f), 5.0f);
+    float const p = szg_powf(1.0f - clampf(dotP(h, lightDir), 0.0f, 1.0f), 5.0f);
     V3 const fresnel = m.reflectance + (splat(1.0f) - m.reflectance) * p;
     return mix(m.diffuse, specular, fresnel);
 }
@@ -1207,8 +1233,8 @@ template <bool LEAN = false> SZG_DEV V3 brdfMix(const Material& m, V3 lightDir, 
 // pbrFunctions.glinl:22-32
 SZG_DEV V3 computeFresnel(const Material& m, V3 lightOutgoing, V3 viewOutgoing)
 {
-    V3 const h = normalize(lightOutgoing + viewOutgoing);
-    float const p = szg_powf(1.0f - clampf(dot(h, lightOutgoing), 0.0f, 1.0f), 5.0f);
+    V3 const h = normalizeP(lightOutgoing + viewOutgoing);
+    float const p = szg_powf(1.0f - clampf(dotP(h, lightOutgoing), 0.0f, 1.0f), 5.0f);
     return m.reflectance + (splat(1.0f) - m.reflectance) * p;
 }
 

@@ -10,8 +10,9 @@ What is asserted: the oracle with its contraction rule switched off (oracle/libs
 -DSZG_ORACLE_LITERAL turns every fused a * b + c of the rule into two roundings) reproduces every vector BIT FOR BIT. So the
 restatement performs the shader's operations, with the shader's constants, in the shader's order, on every path these vectors
 walk (sky, sun disc, ground hits, lit and unlit geometry, reflections, all three light types, PCF shadow taps, both LUT
-kernels). The default oracle - the parity checker of the GPU tests - differs from the literal one only by the documented
-contraction rule (oracle/szg_oracle.cpp header), a freedom the SPIR-V grants (no NoContraction decoration).
+kernels). The default oracle - the parity checker of the GPU tests - differs from the literal one only by the product's
+contraction rule (include/szg/contraction.h: the site classes measured to stay within 1e-4 relative / one UNORM16 step of
+these vectors), a freedom the SPIR-V grants (no NoContraction decoration).
 
 Not pinned, because Vulkan leaves them to the implementation: the values of exp / pow / sin / cos / asin / acos
 (both sides use include/szg/fpmath.h), the texture filter and UNORM conversion models, and where a real GPU contracts.
@@ -192,23 +193,43 @@ def test_gbuffer_fragment_shader(vec):
     assert len(got) == 160
 
 
-def test_the_default_oracle_differs_from_the_literal_one_only_in_the_last_places(vec):
-    """The contraction rule moves values by rounding errors, not by more: the parity oracle against the same vectors."""
-    k = 0
+@pytest.mark.parametrize("k", range(6))
+def test_the_product_rule_stays_within_1e4_and_one_step_of_the_spirv_vectors(vec, k):
+    """The parity oracle (the product's contraction rule, include/szg/contraction.h: the classes measured to be harmless)
+    against the vectors of the literal execution: north_star's 1e-4 relative and one UNORM16 step, on every recorded pixel of
+    lights.comp and camera.comp. Round 2's rule (every class fused) was 2.3e-3 / 7 steps away on the same vectors."""
     frame, atm, cam, dirs, ndirs, spots, nspots, sm, keep = _frame(vec, k)
     H, W = frame.depth.shape
     rect = abi.Rect(0, 0, W, H)
     ob.lights(frame, rect, None, sm, cam, dirs, ndirs, 1, spots, nspots, threads=8)
-    xy = vec[f"lights_xy_{k}"]
-    want = vec[f"lights_value_{k}"].view(np.float32)
-    got = frame.debug[xy[:, 1], xy[:, 0]]
-    assert np.allclose(got, want, rtol=2e-5, atol=1e-7)
-    ob.composite(frame, rect, None, sm, atm, cam, dirs, 0, _tlut(vec, k), np.ascontiguousarray(vec[f"slut_{k}"]), threads=8)
-    xy = vec[f"camera_xy_{k}"]
-    want = vec[f"camera_value_{k}"].view(np.float32)
-    got = frame.debug[xy[:, 1], xy[:, 0]]
-    rel = np.abs(got - want) / np.maximum(np.abs(want), 1e-3)
-    assert np.median(rel) < 1e-5 and rel.max() < 5e-2, (np.median(rel), rel.max())
+    for shader in ("lights", "camera"):
+        if shader == "camera":
+            # (the literal LUT: the product's rule fuses nothing inside transmittance_LUT.comp, test below)
+            ob.composite(frame, rect, None, sm, atm, cam, dirs, 0, _tlut(vec, k), np.ascontiguousarray(vec[f"slut_{k}"]), threads=8)
+        xy = vec[f"{shader}_xy_{k}"]
+        want = vec[f"{shader}_value_{k}"].view(np.float32)
+        got = frame.debug[xy[:, 1], xy[:, 0]]
+        rel = np.abs(got.astype(np.float64) - want) / np.maximum(np.abs(want), 1e-3)
+        assert rel.max() <= 1e-4, (shader, k, rel.max())
+        step = np.abs(frame.color[xy[:, 1], xy[:, 0]].astype(np.int64) - vec[f"{shader}_unorm_{k}"].astype(np.int64))
+        assert step.max() <= 1, (shader, k, step.max())
+
+
+def test_the_product_rule_leaves_the_lut_shaders_at_the_literal_values(vec):
+    """transmittance_LUT.comp: no fused class occurs in it, the default oracle IS the literal one there (whole LUT, SHA-256).
+    skyview_LUT.comp: within 1e-4 of the literal texels (measured 2.2e-7)."""
+    atm = _block(abi.AtmospherePacked, vec["atm_0"])
+    t = ob.transmittance_lut(atm, 512, 128, threads=8)
+    assert hashlib.sha256(t.tobytes()).digest() == bytes(vec["tlut_sha256_0"])
+    W, H = (int(v) for v in vec["skyview_extent"])
+    worst = 0.0
+    for i, (x, y) in enumerate(vec["skyview_xy"]):
+        atm = _block(abi.AtmospherePacked, vec["skyview_atm"][i])
+        cam = _block(abi.CameraPacked, vec["skyview_cam"][i])
+        row = ob.skyview_lut(atm, cam, _tlut(vec, int(vec["skyview_tlut"][i])), W, H, row_begin=int(y), row_end=int(y) + 1, threads=8)
+        want = vec["skyview_texel"][i].view(np.float32).astype(np.float64)
+        worst = max(worst, float((np.abs(row[int(y), int(x)] - want) / np.maximum(np.abs(want), 1e-3)).max()))
+    assert worst <= 1e-4, worst
 
 
 @pytest.mark.skipif(not gen.available(), reason="the reference's committed SPIR-V is only present in the build container")
