@@ -113,10 +113,10 @@ def table(outdir):
         return (f"| {label} | `{m:#05x}` | {p['camera_rel_max']:.1e} | {p['camera_unorm_max_step']} | {p['skyview_rel_max']:.1e} | "
                 f"{p['transmittance_rel_max']:.1e} | {p['lights_rel_max']:.1e} / {p['lights_unorm_max_step']} | "
                 f"{c3.get('ms_per_step', float('nan')):.3f} | {passes.get('composite', float('nan')):.3f} | {passes.get('skyview', float('nan')):.3f} | "
-                f"{r.get('c2', {}).get('ms_per_step', float('nan')):.3f} |")
+                f"{(r.get('c5', {}).get('passes_ms') or {}).get('lights', float('nan')):.3f} |")
 
     head = ("| build | mask | camera.comp rel max | UNORM16 steps | sky-view rel max | transmittance rel max | lights rel / steps | "
-            "C3 frame ms | composite ms | sky-view ms | C2 frame ms |\n|---|---|---|---|---|---|---|---|---|---|---|")
+            "C3 frame ms | composite ms | sky-view ms | C5 lights ms |\n|---|---|---|---|---|---|---|---|---|---|---|")
     print(head)
     print(row("literal (nothing fused)", 0))
     print(row("everything fused (round 2's product)", every))
@@ -124,7 +124,11 @@ def table(outdir):
         print(row(f"only {name} fused", v))
     for name, v in cls.items():
         print(row(f"all but {name} fused", every & ~v))
+    print(row("**the product's rule** (MATVEC, MIX, TEXCOORD, STEP, ACCUM, PBRDOT, LDOT)", 0x3616))
+    print(row("the product's rule + LUTMAP (inside the bar with a margin of 1.5; not taken)", 0x3636))
     for m in sorted(recs):
+        if m in (0x3616, 0x3636):
+            continue
         if m not in (0, every) and m not in cls.values() and m not in [every & ~v for v in cls.values()]:
             print(row("combination", m))
 
