@@ -324,14 +324,19 @@ def main():
     # committed profile of THIS workload (tools/collect_pmc.py: rocprofv3, separate --pmc passes, gfx950 FETCH_SIZE
     # correction) and only when that file names this workload and this kernel.
     roofline_valu = None
-    pmc_path = os.path.join(ROOT, "profiles", f"r02_pmc_{name}.json")
-    if os.path.exists(pmc_path) and not tiled:
+    pmc_path = latest_profile(f"pmc_{name}.json")
+    pmc_rel = os.path.relpath(pmc_path, ROOT) if pmc_path else None
+    if pmc_path and not tiled:
         try:
             prof = json.load(open(pmc_path))
             k = prof["kernels"].get(dominant) if prof.get("workload") == name else None
             if k is not None:
                 roofline["traffic"] = k.get("hbm_bytes_per_launch")
-                roofline["traffic_source"] = f"profiles/r02_pmc_{name}.json"
+                roofline["traffic_source"] = pmc_rel
+                # which tree the counter profile was collected from, and what the kernel took there: counters cannot be
+                # read inside this run, so the line says how far the profile is from what it decorates
+                roofline["traffic_profile"] = {"source_hash": prof.get("source_hash"), "avg_launch_ms": k.get("avg_launch_ms"),
+                                               "same_sources_as_this_run": prof.get("source_hash") == entry.source_hash("hip")}
                 if "valu_issue_cycles_per_launch" in k:
                     # every VALU instruction class priced at its issue cost measured by tools/opcost.hip
                     # (profiles/r02_opcost.txt): what the kernel needs of the 1024 SIMDs if it did nothing but issue
@@ -343,7 +348,7 @@ def main():
                         "class_costs": prof.get("class_issue_cycles"),
                         "clock_GHz_at_which_issue_alone_takes_the_measured_time": cyc / simds / dom_s / 1e9,
                         "frac_of_issue_ceiling_at_2.4GHz": cyc / simds / 2.4e9 / dom_s,
-                        "source": f"profiles/r02_pmc_{name}.json + profiles/r02_opcost.txt",
+                        "source": f"{pmc_rel} + profiles/r02_opcost.txt",
                     }
         except Exception as e:  # a malformed profile must not cost the bench line
             log("profile not usable:", e)
@@ -375,12 +380,12 @@ def main():
         # N = 1 of the default run is the 4K workload the metric is quoted on; the strong-scaling base of THIS workload
         # (same 8K frame on one GPU, untiled) is a committed measurement, repeated here so that the speed-up can be read
         # off the line without mixing workloads.
-        ref = os.path.join(ROOT, "profiles", "r02_bench_c4.json")
-        if os.path.exists(ref):
+        ref = latest_profile("bench_c4.json")
+        if ref:
             try:
                 r1 = json.load(open(ref))
                 out["strong_scaling_reference"] = {"workload": name, "n_gpus": 1, "value": r1["value"], "ms_per_step": r1["ms_per_step"],
-                                                   "image_checksum": r1.get("image_checksum"), "source": "profiles/r02_bench_c4.json",
+                                                   "image_checksum": r1.get("image_checksum"), "source": os.path.relpath(ref, ROOT),
                                                    "speedup_vs_reference": value / r1["value"]}
             except Exception:
                 pass
@@ -566,6 +571,14 @@ def main():
         dist.destroy_process_group()
     deferred.cleanup()
     sky.destroy()
+
+
+def latest_profile(suffix):
+    """profiles/rNN_<suffix> of the latest round that has one (None if no round has)."""
+    import glob
+
+    found = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_{suffix}")))
+    return found[-1] if found else None
 
 
 def self_launch(nproc, real_stdout):

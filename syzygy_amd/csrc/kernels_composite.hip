@@ -224,18 +224,13 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
         float shadowFactor = 1.0f;
         if (sunSlot.map != nullptr)
         {
-            const szg_directional_light_packed* sun = dirLights + sunLightIndex;
-            M4 toTex;
-            {
-                float const t[16] = {0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f,
-                                     0.0f, 0.0f, 1.0f, 0.0f, 0.5f, 0.5f, 0.0f, 1.0f};
+            // TO_TEX * (sun.projection * sun.view): once per frame by k_frame_prep (FramePrep::sunShadow), wave-uniform here
+            M4 sm;
 #pragma unroll
-                for (int k = 0; k < 16; k++)
-                {
-                    toTex.m[k] = t[k];
-                }
+            for (int k = 0; k < 16; k++)
+            {
+                sm.m[k] = prep->sunShadow[k];
             }
-            M4 const sm = mul(toTex, mul(load_m4(sun->projection), load_m4(sun->view)));
             V4 c = mul(sm, m.position.x, m.position.y, m.position.z, 1.0f);
             float const w = c.w;
             V3 const coord = mk3(c.x / w, c.y / w, c.z / w);

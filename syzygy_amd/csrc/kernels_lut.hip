@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void k_lut_range(float4* __restrict__ lut, uns
 
 // One lane: the per-frame constants of szg_device.hpp FramePrep.
 __global__ __launch_bounds__(64) void k_frame_prep(const szg_atmosphere_packed* __restrict__ atmospheres, unsigned atmosphereIndex,
-                                                   int tW, int tH, FramePrep* __restrict__ out)
+                                                   int tW, int tH, FramePrep* __restrict__ out,
+                                                   const szg_directional_light_packed* __restrict__ sun)
 {
     if (threadIdx.x != 0u)
     {
@@ -156,6 +157,28 @@ __global__ __launch_bounds__(64) void k_frame_prep(const szg_atmosphere_packed* 
     f.u_scale = 1.0f - 1.0f / (float)tW;
     f.v_bias = 0.5f / (float)tH;
     f.v_scale = 1.0f - 1.0f / (float)tH;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+        f.sunShadow[k] = 0.0f;
+    }
+    if (sun != nullptr)
+    {
+        // shadowmap.glinl:2-7 TO_TEX_COORD_MAT (column-major literal); camera.comp:366-369
+        M4 toTex;
+        float const t[16] = {0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 0.5f, 0.0f, 0.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.5f, 0.5f, 0.0f, 1.0f};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+            toTex.m[k] = t[k];
+        }
+        M4 const sm = mul(toTex, mul(load_m4(sun->projection), load_m4(sun->view)));
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+        {
+            f.sunShadow[k] = sm.m[k];
+        }
+    }
     *out = f;
 }
 
@@ -496,9 +519,10 @@ hipError_t launch_lut_key(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
 }
 
 size_t frame_prep_bytes() { return sizeof(FramePrep); }
-hipError_t launch_frame_prep(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, unsigned tW, unsigned tH, void* d_prep)
+hipError_t launch_frame_prep(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, unsigned tW, unsigned tH, void* d_prep,
+                             const szg_directional_light_packed* d_sun)
 {
-    hipLaunchKernelGGL(k_frame_prep, dim3(1), dim3(64), 0, s, d_atm, atmIndex, (int)tW, (int)tH, static_cast<FramePrep*>(d_prep));
+    hipLaunchKernelGGL(k_frame_prep, dim3(1), dim3(64), 0, s, d_atm, atmIndex, (int)tW, (int)tH, static_cast<FramePrep*>(d_prep), d_sun);
     return hipGetLastError();
 }
 

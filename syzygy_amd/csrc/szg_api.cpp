@@ -786,7 +786,8 @@ static int record_composite(szg_skyview_t* p, void* stream, const szg_scene_text
     SZG_HIP(ensure_tlut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(ensure_slut_status(p, static_cast<hipStream_t>(stream)));
     SZG_HIP(szg::launch_frame_prep(static_cast<hipStream_t>(stream), d_atmospheres, atmosphere_index, p->desc.transmittance_width,
-                                   p->desc.transmittance_height, p->d_framePrepDraw));
+                                   p->desc.transmittance_height, p->d_framePrepDraw,
+                                   sun.map != nullptr ? d_lights + sun_light_index : nullptr));
     SZG_HIP(szg::launch_composite(static_cast<hipStream_t>(stream), *scene_texture, draw_rect.width, draw_rect.height, t, *gbuffer,
                                   sun, d_atmospheres, atmosphere_index, d_cameras, view_camera_index, d_lights, sun_light_index,
                                   p->d_transmittance, p->desc.transmittance_width, p->desc.transmittance_height, p->d_skyview,

@@ -683,6 +683,10 @@ struct FramePrep
 {
     Atm a;
     float fwidth, fheight, u_bias, u_scale, v_bias, v_scale;
+    // camera.comp:366-369: TO_TEX_COORD_MAT * (sun.projection * sun.view), the shadow frame's matrix of the composite - two 4x4
+    // products that are the same for every pixel (round 2 formed them per lane, ~300 VALU instructions per geometry pixel when a
+    // sun shadow map is bound). Same mul(), same order; read back through scalar loads. Valid when the composite has a sun map.
+    float sunShadow[16];
 };
 // The block arrives through scalar loads; its floats then move to vector registers, where the per-wave derivation used to
 // leave them: a VALU instruction of gfx950 reads at most one scalar operand, and ~70 constants held in scalar registers

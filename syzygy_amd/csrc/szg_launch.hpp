@@ -88,7 +88,10 @@ hipError_t launch_skyview(hipStream_t s, const szg_atmosphere_packed* d_atm, uns
 // Per-frame constants (szg_device.hpp FramePrep): one-lane kernel in front of the sky-view LUT kernel and the composite, which
 // read `d_prep` (frame_prep_bytes() bytes of device memory) instead of deriving the same ~300 instructions' worth in every wave.
 size_t frame_prep_bytes();
-hipError_t launch_frame_prep(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, unsigned tW, unsigned tH, void* d_prep);
+// `d_sun` (may be null): the directional light whose shadow map the composite samples; its TO_TEX * projection * view goes into
+// the block (FramePrep::sunShadow).
+hipError_t launch_frame_prep(hipStream_t s, const szg_atmosphere_packed* d_atm, unsigned atmIndex, unsigned tW, unsigned tH, void* d_prep,
+                             const szg_directional_light_packed* d_sun = nullptr);
 hipError_t launch_light_prep(hipStream_t s, const szg_directional_light_packed* d_dir, unsigned dirCount, unsigned dirSkip,
                              const szg_spot_light_packed* d_spot, unsigned spotCount, const ShadowSlot* d_slots,
                              unsigned slotCount, LightRec* d_out);

@@ -51,6 +51,18 @@ def test_bench_under_an_external_launcher_and_forced_tiling_on_rccl():
     assert one["image_checksum"] == two["image_checksum"]
 
 
+_C4 = {}
+
+
+def _single_gpu_c4_checksum():
+    """The untiled 8K frame rendered by this build in this run (a committed checksum goes stale with every change of the
+    arithmetic, e.g. round 3's contraction rule)."""
+    if "checksum" not in _C4:
+        _C4["checksum"] = _run([sys.executable, "bench.py", "--workload", "c4", "--steps", "1", "--warmup", "0", "--no-cpu-baseline",
+                                "--no-extras"])["image_checksum"]
+    return _C4["checksum"]
+
+
 @pytest.mark.parametrize("ranks", [2, 4])
 def test_n_rank_frame_through_the_c_abi_collectives_on_one_gpu(ranks):
     """The multi-rank frame loop through the C-ABI's OWN collective entry points (szg_rowtile_comm_*, szg_rowtile_gather,
@@ -66,9 +78,7 @@ def test_n_rank_frame_through_the_c_abi_collectives_on_one_gpu(ranks):
     cfg = many["config"]
     assert many["n_gpus"] == ranks and cfg["parallelism"] == f"rowtile{ranks}+gather" and cfg["collectives"] == "nccl"
     assert cfg["collective_api"].startswith("szg_rowtile_comm") and cfg["rccl_ranks"] == ranks
-    with open(os.path.join(ROOT, "profiles", "r02_bench_c4.json")) as f:
-        single = json.load(f)
-    assert many["image_checksum"] == single["image_checksum"]
+    assert many["image_checksum"] == _single_gpu_c4_checksum()
 
 
 def test_bench_roofline_names_the_dominant_kernel_of_each_workload():

@@ -53,6 +53,13 @@ def kernel_key(name):
     return base.split("<")[0].strip()
 
 
+def _source_hash():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as entry
+
+    return entry.source_hash("hip")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", required=True)
@@ -105,6 +112,7 @@ def main():
         kernels[k] = m
     out = {
         "workload": args.workload,
+        "source_hash": _source_hash(),  # the tree the profiled library was built from (__graft_entry__.source_hash("hip"))
         "command": " ".join(bench),
         "tool": "rocprofv3: --kernel-trace --stats alone, then one --pmc pass per counter group (tools/collect_pmc.py)",
         "correction": "gfx950 FETCH_SIZE reports half of the bytes of wide coalesced reads: doubled; WRITE_SIZE exact; both in KB",
