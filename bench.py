@@ -166,6 +166,13 @@ def main():
             comm = rowtile.Comm(rank, world, local_rank)
             collective_api = "szg_rowtile_comm (C-ABI, RCCL)"
         except Exception as e:
+            if getattr(e, "code", None) == abi.SZG_ERR_TIMEOUT:
+                # the rendezvous missed its deadline (SZG_COMM_TIMEOUT_S): ncclCommInitRank is still blocked on a helper thread
+                # and cannot be cancelled. Leave with a non-zero status NOW - that is what makes the launcher tear the other
+                # ranks down - without destructors, without another collective, without re-executing anything.
+                log(f"rank {rank}: {e}; exiting with status 3")
+                sys.stderr.flush()
+                os._exit(3)
             log(f"rank {rank}: szg_rowtile_comm failed ({e}); falling back to torch.distributed's RCCL backend")
             ok = 0
         agreed = torch.tensor([ok], dtype=torch.int32)
@@ -366,10 +373,12 @@ def main():
         "config": {"workload": wl["label"], "width": W, "height": H, "spot_lights": SPOTS, "geometry_fraction": G_frame / (W * H),
                    "sun_elevation_deg": args.elevation, "row_tile_block_rows": BLOCK_ROWS if tiled else None,
                    "parallelism": (f"rowtile{nranks}+gather" if tiled else ("single" if world == 1 else f"replicas{world}")),
-                   "collectives": (args.backend if (world > 1 or args.force_tiled) else None),
-                   "collective_api": collective_api, "rccl_ranks": (comm.size() if comm is not None else None)},
+                   "collectives": (args.backend if (tiled and (world > 1 or args.force_tiled)) else None),  # data-path collectives only
+                   "collective_api": collective_api, "rccl_ranks": (comm.size() if comm is not None else None),
+                   "rccl_bound": (lib().szg_rowtile_comm_backend().decode() if comm is not None else None)},
         "pass_ms_rank0": per,
-        "source_hash": entry.source_hash("hip"),
+        "source_hash": entry.source_hash("hip"),  # the sources on disk ...
+        "library_build_id": lib().szg_build_id().decode(),  # ... and what the loaded binary says it was built from
         "roofline": roofline,
         "roofline_valu": roofline_valu,
         "roofline_frame": {"algorithmic_bytes": frame_bytes, "device_ms": frame_s * 1e3,

@@ -38,6 +38,7 @@ extern "C" {
 #define SZG_ERR_OUT_OF_MEMORY (-3)
 #define SZG_ERR_HIP (-4)
 #define SZG_ERR_CAPACITY (-5)
+#define SZG_ERR_TIMEOUT (-8) /* a collective rendezvous did not complete within its deadline (szg_rowtile_comm_create) */
 
 /* ------------------------------------------------------------------------- */
 /* Packed parameter blocks — byte-identical to renderer/gputypes.hpp:17-126   */
@@ -267,6 +268,11 @@ typedef struct szg_fill_scene
 /* Library                                                                     */
 /* ------------------------------------------------------------------------- */
 int szg_abi_version(void);
+/* What this binary was built from: the hash of its sources that the build stamped into it (__graft_entry__.source_hash("hip"),
+ * passed as -DSZG_SOURCE_HASH), and the contraction mask (szg/contraction.h) it was compiled with: "<hash> contract=0x3616".
+ * "unknown" for a build made by plain `make`. bench.py and smoke() print it, so that a record names the binary that ran,
+ * not the tree that happened to be on disk. */
+const char* szg_build_id(void);
 /* Last error text of the calling thread ("" if none). */
 const char* szg_last_error(void);
 /* Number of visible HIP devices, or a negative status. */
@@ -275,6 +281,16 @@ int szg_device_count(void);
 /* ------------------------------------------------------------------------- */
 /* SkyViewComputePipeline (renderer/pipelines/skyview.hpp:24-51)               */
 /* ------------------------------------------------------------------------- */
+/* STREAM RULE (both pipelines). A pipeline object owns per-pass device state that its record_* calls rewrite in stream
+ * order and its kernels read back: the per-frame constant blocks (one for the LUT passes, one for the composite), the LUT
+ * status words, the LUT-reuse key, the light records of the deferred pipeline. Therefore all record_* calls of ONE
+ * pipeline object must be ordered on ONE stream (or ordered against each other by events), like the reference records
+ * them into one command buffer - with the single exception stated at the calls themselves: the LUT passes
+ * (szg_skyview_record_transmittance / _skyview_lut / _skyview_lut_rows, szg_skyview_allgather_lut_rows) may run on a
+ * second stream than szg_skyview_record_composite, because they use their own constant block; the caller then orders
+ * "LUTs complete" before "composite" with an event. Two composites of the same pipeline recorded on two unordered
+ * streams race on the composite's block: use two pipeline objects for that. Calls from several host threads on one
+ * object need external locking. */
 typedef struct szg_skyview szg_skyview_t;
 
 typedef struct szg_skyview_desc
@@ -521,6 +537,16 @@ typedef struct szg_rowtile_comm szg_rowtile_comm_t;
 #define SZG_ROWTILE_COMM_ID_BYTES 256
 int szg_rowtile_comm_unique_id(void* out_id);
 int szg_rowtile_comm_create(szg_rowtile_comm_t** out, int rank, int nranks, const void* unique_id, int device);
+/* The same with an explicit deadline for the rendezvous (milliseconds; 0 = wait for ever). szg_rowtile_comm_create uses
+ * SZG_COMM_TIMEOUT_S seconds (default 300). When the other ranks do not join in time the call returns SZG_ERR_TIMEOUT:
+ * RCCL's blocking initialisation cannot be cancelled, so the process must then EXIT with a non-zero status (which is what
+ * lets a launcher tear the other ranks down) - do not retry in the same process, and never re-exec a process that has
+ * touched the GPU. */
+int szg_rowtile_comm_create_deadline(szg_rowtile_comm_t** out, int rank, int nranks, const void* unique_id, int device, int timeout_ms);
+/* Which RCCL the collectives are bound to: "<path of the shared object> (RCCL version code N; how it was found; gather: ...)",
+ * or the reason why none could be bound. Binding order: SZG_RCCL_LIBRARY, then an RCCL already mapped into the process
+ * (inside PyTorch: the one torch.distributed uses - never a second copy), then librccl.so.1 by name. SZG_LOG=1 prints it. */
+const char* szg_rowtile_comm_backend(void);
 void szg_rowtile_comm_destroy(szg_rowtile_comm_t* comm);
 int szg_rowtile_comm_rank(const szg_rowtile_comm_t* comm);
 int szg_rowtile_comm_size(const szg_rowtile_comm_t* comm); /* the rank count RCCL reports for the communicator */

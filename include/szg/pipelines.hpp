@@ -235,6 +235,23 @@ private:
     szg_scene_texture m_texture{};
 };
 
+// The reference's record calls return void and log what goes wrong (SZG_ERROR); so do these wrappers: a negative status of
+// the C-ABI call is printed once per call site to stderr with szg_last_error()'s text and kept in the pipeline's
+// lastStatus(), so that a refused pass (e.g. a draw rect with a non-zero offset, szg/abi.h) is never a silently
+// unrendered frame.
+namespace detail
+{
+inline auto note(int status, char const* what, int& last) -> int
+{
+    last = status;
+    if (status < 0)
+    {
+        std::fprintf(stderr, "[szg] %s failed with status %d: %s\n", what, status, szg_last_error());
+    }
+    return status;
+}
+} // namespace detail
+
 // pipelines/deferred.hpp:23-119
 struct DeferredShadingPipeline
 {
@@ -263,11 +280,11 @@ struct DeferredShadingPipeline
                             TStagedBuffer<CameraPacked> const& cameras, szg_fill_scene const* sceneGeometry,
                             szg_rowtile const* tile = nullptr)
     {
-        (void)szg_deferred_record_draw_commands(m_handle, cmd, drawRect, tile, &sceneTexture.texture(),
+        detail::note(szg_deferred_record_draw_commands(m_handle, cmd, drawRect, tile, &sceneTexture.texture(),
                                                 atmosphericDirectionalLightsCount, directionalLights.deviceAddress(),
                                                 static_cast<uint32_t>(directionalLights.deviceSize()), spotLights.data(),
                                                 static_cast<uint32_t>(spotLights.size()), viewCameraIndex,
-                                                cameras.deviceAddress(), sceneGeometry);
+                                                cameras.deviceAddress(), sceneGeometry), "szg_deferred_record_draw_commands", m_lastStatus);
     }
     // deferred.hpp:34-44 with the reference's own last argument, std::span<MeshInstanced const> sceneGeometry
     // (szg/raster.h): shadow raster, G-buffer raster, lights.
@@ -278,13 +295,14 @@ struct DeferredShadingPipeline
                             TStagedBuffer<CameraPacked> const& cameras, std::span<szg_mesh_instanced const> sceneGeometry,
                             szg_rowtile const* tile = nullptr)
     {
-        (void)szg_deferred_record_draw_commands_meshes(m_handle, cmd, drawRect, tile, &sceneTexture.texture(),
+        detail::note(szg_deferred_record_draw_commands_meshes(m_handle, cmd, drawRect, tile, &sceneTexture.texture(),
                                                        atmosphericDirectionalLightsCount, directionalLights.deviceAddress(),
                                                        static_cast<uint32_t>(directionalLights.deviceSize()), spotLights.data(),
                                                        static_cast<uint32_t>(spotLights.size()), viewCameraIndex,
                                                        cameras.deviceAddress(), sceneGeometry.data(),
-                                                       static_cast<uint32_t>(sceneGeometry.size()));
+                                                       static_cast<uint32_t>(sceneGeometry.size())), "szg_deferred_record_draw_commands_meshes", m_lastStatus);
     }
+    [[nodiscard]] auto lastStatus() const -> int { return m_lastStatus; } // status of the last record call (SZG_OK or negative)
     [[nodiscard]] auto gbuffer() -> szg_gbuffer const& { return *szg_deferred_gbuffer(m_handle); }          // deferred.hpp:46
     [[nodiscard]] auto shadowMaps() -> szg_shadowmaps const& { return *szg_deferred_shadow_maps(m_handle); } // deferred.hpp:47
     void cleanup() // deferred.hpp:49
@@ -303,6 +321,7 @@ struct DeferredShadingPipeline
 
 private:
     szg_deferred_t* m_handle{nullptr};
+    int m_lastStatus{SZG_OK};
 };
 
 // pipelines/skyview.hpp:24-51
@@ -333,12 +352,13 @@ struct SkyViewComputePipeline
                             TStagedBuffer<CameraPacked> const& cameras, uint32_t sunLightIndex,
                             TStagedBuffer<DirectionalLightPacked> const& lights, szg_rowtile const* tile = nullptr)
     {
-        (void)szg_skyview_record_draw_commands(m_handle, cmd, &sceneTexture.texture(), drawRect, tile, &gbuffer, &shadowMaps,
+        detail::note(szg_skyview_record_draw_commands(m_handle, cmd, &sceneTexture.texture(), drawRect, tile, &gbuffer, &shadowMaps,
                                                atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
-                                               cameras.deviceAddress(), sunLightIndex, lights.deviceAddress());
+                                               cameras.deviceAddress(), sunLightIndex, lights.deviceAddress()), "szg_skyview_record_draw_commands", m_lastStatus);
     }
     // ---- extensions without a reference counterpart (szg/abi.h) ----
     // LUT reuse across frames whose atmosphere / sun / camera position are unchanged (identical results)
+    [[nodiscard]] auto lastStatus() const -> int { return m_lastStatus; } // status of the last record call (SZG_OK or negative)
     void setLUTReuse(bool enable) { (void)szg_skyview_set_lut_reuse(m_handle, enable ? 1 : 0); }
     void invalidateLUTs(uint32_t which = SZG_LUT_TRANSMITTANCE | SZG_LUT_SKYVIEW) { (void)szg_skyview_invalidate_luts(m_handle, which); }
     // Row-tiled multi-GPU frame: transmittance LUT, this rank's slice of the sky-view LUT, the all-gather of the slices on
@@ -351,14 +371,14 @@ struct SkyViewComputePipeline
                                  TStagedBuffer<DirectionalLightPacked> const& lights, szg_rowtile const& tile)
     {
         uint32_t begin = 0, end = 0;
-        (void)szg_skyview_record_transmittance(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress());
+        detail::note(szg_skyview_record_transmittance(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress()), "szg_skyview_record_transmittance", m_lastStatus);
         if (szg_skyview_lut_row_slice(m_handle, tile.rank, tile.nranks, &begin, &end) == SZG_OK)
         {
-            (void)szg_skyview_record_skyview_lut_rows(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
-                                                      cameras.deviceAddress(), begin, end);
+            detail::note(szg_skyview_record_skyview_lut_rows(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
+                                                      cameras.deviceAddress(), begin, end), "szg_skyview_record_skyview_lut_rows", m_lastStatus);
             (void)hipEventRecord(scratchEvent, cmd);
             (void)hipStreamWaitEvent(lutStream, scratchEvent, 0);
-            (void)szg_skyview_allgather_lut_rows(m_handle, comm, lutStream);
+            detail::note(szg_skyview_allgather_lut_rows(m_handle, comm, lutStream), "szg_skyview_allgather_lut_rows", m_lastStatus);
             (void)hipEventRecord(scratchEvent, lutStream);
             (void)hipStreamWaitEvent(cmd, scratchEvent, 0);
         }
@@ -366,12 +386,12 @@ struct SkyViewComputePipeline
         {
             // the LUT's rows do not divide over the ranks (every rank sees that alike): each rank computes the whole LUT,
             // as the single-GPU frame does, and the optional second collective is skipped
-            (void)szg_skyview_record_skyview_lut(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
-                                                 cameras.deviceAddress());
+            detail::note(szg_skyview_record_skyview_lut(m_handle, cmd, atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex,
+                                                 cameras.deviceAddress()), "szg_skyview_record_skyview_lut", m_lastStatus);
         }
-        (void)szg_skyview_record_composite(m_handle, cmd, &sceneTexture.texture(), drawRect, &tile, &gbuffer, &shadowMaps,
+        detail::note(szg_skyview_record_composite(m_handle, cmd, &sceneTexture.texture(), drawRect, &tile, &gbuffer, &shadowMaps,
                                            atmosphereIndex, atmospheres.deviceAddress(), viewCameraIndex, cameras.deviceAddress(),
-                                           sunLightIndex, lights.deviceAddress());
+                                           sunLightIndex, lights.deviceAddress()), "szg_skyview_record_composite", m_lastStatus);
     }
     [[nodiscard]] auto transmittanceLUT() const -> szg_image
     {
@@ -389,5 +409,6 @@ struct SkyViewComputePipeline
 private:
     explicit SkyViewComputePipeline(szg_skyview_t* h) : m_handle(h) {}
     szg_skyview_t* m_handle{nullptr};
+    int m_lastStatus{SZG_OK};
 };
 } // namespace szg

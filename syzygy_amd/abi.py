@@ -11,6 +11,11 @@ import numpy as np
 SZG_ABI_VERSION = 1
 
 SZG_OK = 0
+SZG_ERR_INVALID_ARGUMENT = -1
+SZG_ERR_NO_DEVICE = -2
+SZG_ERR_OUT_OF_MEMORY = -3
+SZG_ERR_HIP = -4
+SZG_ERR_CAPACITY = -5
 
 SZG_AERIAL_W = SZG_AERIAL_H = SZG_AERIAL_D = 32
 SZG_OETF_PURE_GAMMA = 0
@@ -349,6 +354,7 @@ P = C.POINTER
 
 ABI_FUNCTIONS = {
     "szg_abi_version": (C.c_int, []),
+    "szg_build_id": (C.c_char_p, []),
     "szg_last_error": (C.c_char_p, []),
     "szg_device_count": (C.c_int, []),
     "szg_skyview_create": (C.c_int, [P(VP), P(SkyviewDesc), C.c_int]),
@@ -379,6 +385,8 @@ ABI_FUNCTIONS = {
     "szg_skyview_allgather_lut_rows": (C.c_int, [VP, VP, VP]),
     "szg_rowtile_comm_unique_id": (C.c_int, [VP]),
     "szg_rowtile_comm_create": (C.c_int, [P(VP), C.c_int, C.c_int, VP, C.c_int]),
+    "szg_rowtile_comm_create_deadline": (C.c_int, [P(VP), C.c_int, C.c_int, VP, C.c_int, C.c_int]),
+    "szg_rowtile_comm_backend": (C.c_char_p, []),
     "szg_rowtile_comm_destroy": (None, [VP]),
     "szg_rowtile_comm_rank": (C.c_int, [VP]),
     "szg_rowtile_comm_size": (C.c_int, [VP]),
@@ -420,6 +428,7 @@ RASTER_FUNCTIONS = {
 # include/szg/assets.h
 SZG_ERR_IO = -6
 SZG_ERR_PARSE = -7
+SZG_ERR_TIMEOUT = -8
 SZG_GLTF_DECODE_BUFFER_VIEW_IMAGES = 1
 SZG_MAP_COLOR, SZG_MAP_NORMAL, SZG_MAP_ORM = 0, 1, 2
 SZG_DEFAULT_MAP_DIMENSIONS = 64

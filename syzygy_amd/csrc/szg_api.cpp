@@ -16,6 +16,10 @@
 #include <vector>
 
 #include "szg/abi.h"
+#ifdef SZG_LITERAL
+#define SZG_CONTRACT SZG_CONTRACT_NONE
+#endif
+#include "szg/contraction.h"
 #include "szg_internal.hpp"
 #include "szg_launch.hpp"
 
@@ -367,6 +371,17 @@ void szg::set_last_error(const char* message)
 extern "C" {
 
 int szg_abi_version(void) { return SZG_ABI_VERSION; }
+
+#ifndef SZG_SOURCE_HASH
+#define SZG_SOURCE_HASH "unknown"
+#endif
+const char* szg_build_id(void)
+{
+    static char text[64];
+    static std::once_flag once;
+    std::call_once(once, [] { snprintf(text, sizeof text, "%s contract=0x%04x", SZG_SOURCE_HASH, (unsigned)(SZG_CONTRACT)); });
+    return text;
+}
 const char* szg_last_error(void) { return g_error; }
 
 int szg_device_count(void)

@@ -207,11 +207,99 @@ ncclResult_t ncclGather(const void* sendbuff, void* recvbuff, size_t sendcount, 
     return ncclSuccess;
 }
 
-// bound by szg_comm.cpp but only used when ncclGather is absent
-ncclResult_t ncclSend(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclInvalidUsage; }
-ncclResult_t ncclRecv(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) { return ncclInvalidUsage; }
-ncclResult_t ncclGroupStart() { return ncclSuccess; }
-ncclResult_t ncclGroupEnd() { return ncclSuccess; }
+// Grouped point-to-point calls (szg_rowtile_gather's path when the library has no ncclGather, or SZG_RCCL_NO_GATHER is set):
+// like RCCL, Send / Recv inside a group only RECORD the operation; ncclGroupEnd carries the whole group out. Every rank of the
+// communicator takes part in every group (true for the gather: the root receives from all, the others send to it): senders
+// stage their bytes in their slot, a barrier, receivers copy from the peers' slots, a barrier. A call outside a group is a
+// group of one. An operation on a peer outside the communicator fails at the call, inside the open group - which the caller
+// must still close.
+namespace
+{
+struct Pending
+{
+    bool send;
+    const void* src;
+    void* dst;
+    size_t bytes;
+    int peer;
+    MockComm* comm;
+    hipStream_t stream;
+};
+thread_local int g_depth = 0;
+thread_local Pending g_ops[64];
+thread_local int g_nops = 0;
+
+ncclResult_t flush()
+{
+    ncclResult_t result = ncclSuccess;
+    MockComm* c = g_nops > 0 ? g_ops[0].comm : nullptr;
+    for (int i = 0; i < g_nops; i++)
+    {
+        const Pending& o = g_ops[i];
+        if (o.send && (hipStreamSynchronize(o.stream) != hipSuccess ||
+                       hipMemcpy(slot(o.comm, o.comm->rank), o.src, o.bytes, hipMemcpyDeviceToHost) != hipSuccess))
+        {
+            result = ncclUnhandledCudaError;
+        }
+    }
+    if (c != nullptr)
+    {
+        barrier(c);
+    }
+    for (int i = 0; i < g_nops; i++)
+    {
+        const Pending& o = g_ops[i];
+        if (!o.send && (hipStreamSynchronize(o.stream) != hipSuccess || hipMemcpy(o.dst, slot(o.comm, o.peer), o.bytes, hipMemcpyHostToDevice) != hipSuccess))
+        {
+            result = ncclUnhandledCudaError;
+        }
+    }
+    if (c != nullptr)
+    {
+        barrier(c);
+    }
+    g_nops = 0;
+    return result;
+}
+
+ncclResult_t record(bool send, const void* src, void* dst, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    MockComm* c = reinterpret_cast<MockComm*>(comm);
+    if (datatype != ncclUint8 || count > SLOT_BYTES || peer < 0 || peer >= c->nranks || peer == c->rank || g_nops >= 64)
+    {
+        return ncclInvalidArgument;
+    }
+    g_ops[g_nops++] = Pending{send, src, dst, count, peer, c, stream};
+    return g_depth == 0 ? flush() : ncclSuccess;
+}
+} // namespace
+
+ncclResult_t ncclSend(const void* sendbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    return record(true, sendbuff, nullptr, count, datatype, peer, comm, stream);
+}
+ncclResult_t ncclRecv(void* recvbuff, size_t count, ncclDataType_t datatype, int peer, ncclComm_t comm, hipStream_t stream)
+{
+    return record(false, nullptr, recvbuff, count, datatype, peer, comm, stream);
+}
+ncclResult_t ncclGroupStart()
+{
+    g_depth++;
+    return ncclSuccess;
+}
+ncclResult_t ncclGroupEnd()
+{
+    if (g_depth <= 0)
+    {
+        return ncclInvalidUsage;
+    }
+    return --g_depth == 0 ? flush() : ncclSuccess;
+}
+ncclResult_t ncclGetVersion(int* version)
+{
+    *version = -1; // not a real RCCL
+    return ncclSuccess;
+}
 const char* ncclGetErrorString(ncclResult_t e) { return e == ncclSuccess ? "success" : "mock RCCL error"; }
 
 } // extern "C"

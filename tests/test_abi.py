@@ -141,3 +141,16 @@ def test_host_raster_helpers_need_no_device():
     lib().szg_transform_matrix(abi.f3(1, 2, 3), abi.f3(0, 0, 0), abi.f3(2, 2, 2), C.byref(m))
     a = m.to_numpy()
     assert a[0, 0] == 2.0 and a[0, 3] == 1.0 and a[1, 3] == 2.0 and a[2, 3] == 3.0 and a[3, 3] == 1.0
+
+
+def test_collectives_bind_the_rccl_that_is_already_in_the_process():
+    """Inside a PyTorch process the C-ABI's collectives must use the RCCL torch.distributed uses (it is already mapped), never a
+    second copy loaded by SONAME from /opt/rocm; SZG_RCCL_LIBRARY is the explicit override (szg_comm.cpp)."""
+    import torch  # noqa: F401  (maps torch/lib/librccl.so)
+
+    info = lib().szg_rowtile_comm_backend().decode()
+    if "SZG_RCCL_LIBRARY" in os.environ:
+        assert os.environ["SZG_RCCL_LIBRARY"] in info
+    else:
+        assert "already mapped in this process" in info and "librccl" in info and os.path.dirname(torch.__file__) in info, info
+    assert "RCCL version code" in info

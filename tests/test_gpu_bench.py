@@ -63,8 +63,8 @@ def _single_gpu_c4_checksum():
     return _C4["checksum"]
 
 
-@pytest.mark.parametrize("ranks", [2, 4])
-def test_n_rank_frame_through_the_c_abi_collectives_on_one_gpu(ranks):
+@pytest.mark.parametrize("ranks,no_gather", [(2, False), (4, False), (2, True)])
+def test_n_rank_frame_through_the_c_abi_collectives_on_one_gpu(ranks, no_gather):
     """The multi-rank frame loop through the C-ABI's OWN collective entry points (szg_rowtile_comm_*, szg_rowtile_gather,
     szg_skyview_allgather_lut_rows with the status-word exchange) with N real processes on one GPU. RCCL itself cannot run
     there (it refuses two ranks on a device), so tests/cpp/mock_rccl.cpp stands in for librccl.so behind SZG_RCCL_LIBRARY:
@@ -73,12 +73,29 @@ def test_n_rank_frame_through_the_c_abi_collectives_on_one_gpu(ranks):
     two frames in flight, the compose. The composed 8K image must have the checksum of the single-GPU frame."""
     subprocess.run(["make", "-s", "-C", os.path.join(ROOT, "tests", "cpp"), "libmock_rccl.so"], check=True)
     env = {"SZG_RCCL_LIBRARY": os.path.join(ROOT, "tests", "cpp", "libmock_rccl.so")}
+    if no_gather:  # szg_rowtile_gather's grouped ncclSend / ncclRecv form (what a library without ncclGather gets)
+        env["SZG_RCCL_NO_GATHER"] = "1"
     many = _run([sys.executable, "bench.py", "--gpus", str(ranks), "--backend", "nccl", "--same-device", "--steps", "2", "--warmup", "1",
                  "--no-cpu-baseline"], env=env)
     cfg = many["config"]
     assert many["n_gpus"] == ranks and cfg["parallelism"] == f"rowtile{ranks}+gather" and cfg["collectives"] == "nccl"
     assert cfg["collective_api"].startswith("szg_rowtile_comm") and cfg["rccl_ranks"] == ranks
     assert many["image_checksum"] == _single_gpu_c4_checksum()
+
+
+def test_replicas_line_of_the_batch_workload_through_the_self_launcher():
+    """`bench.py --gpus N --workload c5` (BASELINE's config 5: independent 4K views, one per GPU, no collective in the data
+    path): bench.py starts its own ranks, every rank renders the same view, the line reports N x the pixels over the slowest
+    rank's time with "replicas N" / weak scaling. Two ranks share the one GPU of the box here (--same-device), so the value
+    says nothing; what is checked is the launch path, the aggregation and that no collective API is involved."""
+    one = _run([sys.executable, "bench.py", "--workload", "c5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    two = _run([sys.executable, "bench.py", "--gpus", "2", "--workload", "c5", "--backend", "gloo", "--same-device", "--steps", "2",
+                "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
+    assert two["n_gpus"] == 2 and two["scaling"] == "weak" and two["config"]["parallelism"] == "replicas2"
+    assert two["config"]["collectives"] is None and two["config"]["rccl_ranks"] is None
+    assert two["image_checksum"] == one["image_checksum"]
+    # value = pixels of BOTH views / time of the slowest rank
+    assert two["value"] == pytest.approx(2 * 3840 * 2160 / (two["ms_per_step"] * 1e-3) / 1e6, rel=1e-6)
 
 
 def test_bench_roofline_names_the_dominant_kernel_of_each_workload():

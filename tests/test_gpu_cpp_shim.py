@@ -3,6 +3,7 @@ caller renders a frame through the C-ABI; the result must equal the oracle's on 
 scene."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -271,17 +272,21 @@ def test_cpp_tiled_frame_through_the_c_abi_collectives(tmp_path):
     assert a.shape == b.shape and (a == b).all()
 
 
-@pytest.mark.parametrize("ranks", [2, 3])
-def test_cpp_n_rank_tiled_frame_through_the_c_abi_collectives(tmp_path, ranks):
+@pytest.mark.parametrize("ranks,no_gather", [(2, False), (3, False), (3, True)])
+def test_cpp_n_rank_tiled_frame_through_the_c_abi_collectives(tmp_path, ranks, no_gather):
     """The same C++ caller as N processes (no Python, no torch inside them): rank 0 publishes the communicator id in a file,
     every rank renders its cyclic 8-row blocks, the sky-view LUT slices and their status words are all-gathered, the tiles
     gathered to rank 0 and composed. The processes share the one GPU of the box, where RCCL cannot run two ranks, so
     tests/cpp/mock_rccl.cpp stands in for librccl.so (SZG_RCCL_LIBRARY); everything else is the product's C-ABI. The frame
     must equal the plain single-process frame bit for bit. With 3 ranks the 1024 rows of the sky-view LUT do not divide: every
-    rank then computes the whole LUT and the optional second collective is skipped (pipelines.hpp) - same frame."""
+    rank then computes the whole LUT and the optional second collective is skipped (pipelines.hpp) - same frame.
+    `no_gather` (SZG_RCCL_NO_GATHER): szg_rowtile_gather takes its grouped ncclSend / ncclRecv path - the one a library
+    without ncclGather gets - with the root's own tile copied outside the group."""
     exe = os.path.join(HERE, "cpp", "record_draw")
     subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpp"), "record_draw", "libmock_rccl.so"], check=True)
-    env = dict(os.environ, SZG_RCCL_LIBRARY=os.path.join(HERE, "cpp", "libmock_rccl.so"))
+    env = dict(os.environ, SZG_RCCL_LIBRARY=os.path.join(HERE, "cpp", "libmock_rccl.so"), SZG_LOG="1")
+    if no_gather:
+        env["SZG_RCCL_NO_GATHER"] = "1"
     W, H = 200, 240
     plain, tiled, idfile = tmp_path / "plain.bin", tmp_path / "tiled.bin", tmp_path / "comm.id"
     r = subprocess.run([exe, str(plain), str(W), str(H)], capture_output=True, text=True, timeout=300)
@@ -292,6 +297,48 @@ def test_cpp_n_rank_tiled_frame_through_the_c_abi_collectives(tmp_path, ranks):
     for p, (so, se) in zip(procs, outs):
         assert p.returncode == 0, se + so
         assert f"ranks {ranks}" in so
+        assert ("gather: grouped ncclSend/ncclRecv" if no_gather else "gather: ncclGather") in se, se  # SZG_LOG: what was bound
     a = np.fromfile(plain, dtype=np.uint16)
     b = np.fromfile(tiled, dtype=np.uint16)
     assert a.shape == b.shape and (a == b).all()
+
+
+def test_comm_create_deadline_and_error_paths_of_the_grouped_gather(tmp_path):
+    """(a) A rank whose peers never arrive: szg_rowtile_comm_create_deadline returns SZG_ERR_TIMEOUT after its deadline instead
+    of hanging in ncclCommInitRank, and the process then exits non-zero (what makes a launcher tear the job down). Run in a
+    child process: the blocked initialisation cannot be cancelled, only left behind by exiting.
+    (b) An error inside the grouped send / recv path closes the group: a gather to a root outside the communicator is refused
+    up front, and after a failing call the next, valid, gather on the same communicator still works (world of one)."""
+    subprocess.run(["make", "-s", "-C", os.path.join(HERE, "cpp"), "libmock_rccl.so"], check=True)
+    env = dict(os.environ, SZG_RCCL_LIBRARY=os.path.join(HERE, "cpp", "libmock_rccl.so"), SZG_RCCL_NO_GATHER="1")
+    code = r"""
+import ctypes as C, sys, time
+import torch
+import syzygy_amd
+from syzygy_amd import abi
+lib = syzygy_amd.lib()
+ident = (C.c_ubyte * 256)()
+assert lib.szg_rowtile_comm_unique_id(ident) == 0
+# (b) world of one, grouped path
+comm = C.c_void_p()
+assert lib.szg_rowtile_comm_create_deadline(C.byref(comm), 0, 1, ident, 0, 5000) == 0
+tile = torch.arange(4096, dtype=torch.uint8, device="cuda")
+out = torch.zeros(4096, dtype=torch.uint8, device="cuda")
+assert lib.szg_rowtile_gather(comm, None, tile.data_ptr(), 4096, out.data_ptr(), 3) == abi.SZG_ERR_INVALID_ARGUMENT
+assert lib.szg_rowtile_gather(comm, None, tile.data_ptr(), 4096, out.data_ptr(), 0) == 0
+torch.cuda.synchronize()
+assert bool((out == tile).all())
+lib.szg_rowtile_comm_destroy(comm)
+# (a) rank 0 of 2, nobody else comes
+assert lib.szg_rowtile_comm_unique_id(ident) == 0
+t0 = time.time()
+rc = lib.szg_rowtile_comm_create_deadline(C.byref(comm), 0, 2, ident, 0, 700)
+dt = time.time() - t0
+print("rc", rc, "dt", round(dt, 2), lib.szg_last_error().decode())
+sys.stdout.flush()
+import os
+os._exit(3 if rc == abi.SZG_ERR_TIMEOUT and 0.6 < dt < 10 else 0)
+"""
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300, cwd=os.path.dirname(HERE))
+    assert r.returncode == 3, r.stdout + r.stderr
+    assert "did not join within 700 ms" in r.stdout
