@@ -289,6 +289,16 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
     }
     r.rcpFalloffDistance = r.leanOK != 0u ? rcpN(r.falloffDistance) : 0.0f;
     r.falloffBound = r.falloffFactor * r.rcpFalloffDistance * r.rcpFalloffDistance;
+    if (r.leanOK != 0u)
+    {
+        bool tight = fabsf(r.position[0]) <= 0x1p12f && fabsf(r.position[1]) <= 0x1p12f && fabsf(r.position[2]) <= 0x1p12f &&
+                     inRange(r.falloffBound, 0x1p-20f, 0x1p20f);
+        for (int k = 0; k < 16; k++)
+        {
+            tight = tight && fabsf(r.shadowRows[k]) <= 0x1p14f;
+        }
+        r.leanOK |= tight ? 2u : 0u;
+    }
     out[i] = r;
 }
 
@@ -321,8 +331,17 @@ SZG_DEV float sqrtU(bool lean, float x) { return lean ? sqrtN(x) : sqrtf(x); }
 // exact evaluation share one evaluation of the three rows; R[k] * 1.0f of the shader's product is R[k] itself)
 // `backCull` (per lane): the pixel's own factors are of ordinary magnitude (k_lights, pixelModerate), so that a term whose last
 // factor clamp(N.L, 0, 1) is 0 is an exact zero and its BRDF (half of the cost of a lit pair) need not be evaluated.
+//
+// OPTIMISTIC (k_lights' first pass, only for lights whose record is "tight" and waves whose pixels all are, see there): the lean
+// exact operators are used without testing their operand ranges pair by pair. Upper bounds hold by construction; the LOWER
+// bounds (|w| and d^2 >= 2^-30, |half vector|^2 >= 2^-40, projected numerators >= 2^-60 in magnitude - a numerator of exactly
+// 0 counts as out of range here, which only costs time) are folded into `track`, a running minimum per lane, scaled to the
+// common threshold 2^-30: three v_min3 and three multiplies instead of fourteen compares and the mask arithmetic around
+// them. Every operand is a finite number on this path (no NaN can hide from the minimum). k_lights checks `track` once after
+// the loop and repeats the wave's loop with the tested form if it ever fell below the threshold.
+template <bool OPTIMISTIC>
 SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool positionModerate, V3 viewDirection, bool cullable, V3 clip,
-                             bool backCull)
+                             bool backCull, float& track)
 {
     const float* R = L.shadowRows;
     float const cx = clip.x, cy = clip.y, cw = clip.z;
@@ -341,7 +360,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     //   falloff gives spectral = 0).
     // Then nothing of this light needs evaluating for the pixel: a quarter of the lit pixel-light pairs of the bench scenes.
     float const ndl = dotL(m.normal, lightDir);
-    if (backCull && cullable && isSpot && L.leanOK != 0u && !(ndl > 0.0f) && L.falloffBound * d2 >= 0x1p-28f)
+    if (backCull && cullable && isSpot && (OPTIMISTIC || L.leanOK != 0u) && !(ndl > 0.0f) && L.falloffBound * d2 >= 0x1p-28f)
     {
         return splat(0.0f);
     }
@@ -356,12 +375,29 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
     float const cz = (L.map != nullptr)
                          ? SZG_CON(SZG_C_MATVEC, R[10], m.position.z, SZG_CON(SZG_C_MATVEC, R[9], m.position.y, R[8] * m.position.x)) + R[11]
                          : 0.0f;
-    bool const lean = waveAll(L.leanOK != 0u && positionModerate && inRange(fabsf(cw), lo, hi) && inRange(d2, lo, hi) &&
-                            inRange(hd, 0x1p-40f, 8.0f) && leanNumerator(cx) && leanNumerator(cy) && leanNumerator(cz));
+    bool lean = true;
+    if (OPTIMISTIC)
+    {
+        track = fminf(track, fminf(fabsf(cw), d2));
+        track = fminf(track, fminf(hd * 0x1p10f, fabsf(cx) * 0x1p30f));
+        track = fminf(track, fabsf(cy) * 0x1p30f);
+        if (L.map != nullptr)
+        {
+            track = fminf(track, fabsf(cz) * 0x1p30f);
+        }
+    }
+    else
+    {
+        lean = waveAll(L.leanOK != 0u && positionModerate && inRange(fabsf(cw), lo, hi) && inRange(d2, lo, hi) &&
+                       inRange(hd, 0x1p-40f, 8.0f) && leanNumerator(cx) && leanNumerator(cy) && leanNumerator(cz));
+    }
 
     float const ycw = lean ? rcpN(cw) : 0.0f;
-    float const sx = divU(lean, cx, cw, ycw);
-    float const sy = divU(lean, cy, cw, ycw);
+    // (OPTIMISTIC: the quotients below are never zero - numerators >= 2^-60 over denominators < 2^28, positive lengths - so the
+    // sign fix of a zero quotient, divR's last instruction, has nothing to do: divR0; and the square roots of d^2 and |h|^2 are
+    // of numbers >= 2^-40: sqrtP)
+    float const sx = OPTIMISTIC ? divR0(cx, cw, ycw) : divU(lean, cx, cw, ycw);
+    float const sy = OPTIMISTIC ? divR0(cy, cw, ycw) : divU(lean, cy, cw, ycw);
     float edgeSoftening = 1.0f;
     float lightFalloff = 1.0f;
     if (isSpot)
@@ -377,14 +413,15 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
         }
         float const distanceUV = clampf(sqrtU(lean, q) * 2.0f, 0.0f, 1.0f);
         edgeSoftening = 1.0f - distanceUV * distanceUV;
-        float const dist = sqrtU(lean, d2);
-        float const nd = lean ? divR(dist, L.falloffDistance, L.rcpFalloffDistance) : dist / L.falloffDistance;
+        float const dist = OPTIMISTIC ? sqrtP(d2) : sqrtU(lean, d2);
+        float const nd = OPTIMISTIC ? divR0(dist, L.falloffDistance, L.rcpFalloffDistance)
+                                    : (lean ? divR(dist, L.falloffDistance, L.rcpFalloffDistance) : dist / L.falloffDistance);
         lightFalloff = L.falloffFactor * nd * nd;
     }
     float shadow = 1.0f;
     if (L.map != nullptr)
     {
-        float const sz = divU(lean, cz, cw, ycw);
+        float const sz = OPTIMISTIC ? divR0(cz, cw, ycw) : divU(lean, cz, cw, ycw);
         // projectedNormal = shadowMatrix * vec4(normal, 0)
         float const nx = SZG_CON(SZG_C_MATVEC, R[3], 0.0f, SZG_CON(SZG_C_MATVEC, R[2], m.normal.z, SZG_CON(SZG_C_MATVEC, R[1], m.normal.y, R[0] * m.normal.x)));
         float const ny = SZG_CON(SZG_C_MATVEC, R[7], 0.0f, SZG_CON(SZG_C_MATVEC, R[6], m.normal.z, SZG_CON(SZG_C_MATVEC, R[5], m.normal.y, R[4] * m.normal.x)));
@@ -406,13 +443,23 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
         spectral = cs * shadow;
     }
     // computeLightContribution, lights.comp:93-108 (brdfMix of szg_device.hpp with the half vector shared above)
-    float const hinv = lean ? divN(1.0f, sqrtN(hd)) : 1.0f / sqrtf(hd);
+    float const hinv = OPTIMISTIC ? divN0(1.0f, sqrtP(hd)) : (lean ? divN(1.0f, sqrtN(hd)) : 1.0f / sqrtf(hd));
     V3 const h = hs * hinv;
     // both pow() without their special-case selects when no lane of the wave has a zero / denormal / non-finite base or a
     // zero exponent (szg_device.hpp powLean: the same values)
     float const baseSpecular = clampf(dotP(h, m.normal), 0.0f, 1.0f);
     float const baseFresnel = 1.0f - clampf(dotP(h, lightDir), 0.0f, 1.0f);
-    bool const powsLean = waveAll(powLeanOK(baseSpecular, m.specularPower) && powLeanOK(baseFresnel, 5.0f));
+    // (OPTIMISTIC: both bases lie in [0, 1] and must be >= 2^-126 for powLean: tracked like the other lower bounds, x * 2^96
+    // against 2^-30; the exponent's range is part of the wave's precondition in k_lights)
+    bool powsLean = true;
+    if (OPTIMISTIC)
+    {
+        track = fminf(track, fminf(baseSpecular * 0x1p96f, baseFresnel * 0x1p96f));
+    }
+    else
+    {
+        powsLean = waveAll(powLeanOK(baseSpecular, m.specularPower) && powLeanOK(baseFresnel, 5.0f));
+    }
     float const microfacet = powsLean ? powLean(baseSpecular, m.specularPower) : szg_powf(baseSpecular, m.specularPower);
     V3 const specular = splat(m.normalization * microfacet);
     float const p = powsLean ? powLean(baseFresnel, 5.0f) : szg_powf(baseFresnel, 5.0f);
@@ -456,13 +503,43 @@ SZG_DEV bool surelyOutsideCone(V3 clip)
     float const acw = fabsf(cw);
     float const ax = fabsf(cx - 0.5f * cw);
     float const ay = fabsf(cy - 0.5f * cw);
-    // one axis outside implies q = dx^2 + dy^2 >= 0.25 only if the other axis is a number: with a NaN there (inf - inf in a
-    // projection with entries near FLT_MAX) q is NaN, the exact test q >= 0.25 fails and the light contributes in full
-    float const both = ax + ay;
-    return acw > 0.0f && both == both && (ax > 0.505f * acw || ay > 0.505f * acw);
+    // (one axis outside implies q = dx^2 + dy^2 >= 0.25 only if the other axis is a number. It is: the test is only consulted
+    // for a `cullable` pair - every position of the wave finite and <= 2^30, every row of the light <= 2^28 - so the three
+    // projected coordinates are finite numbers below 2^60 and no inf - inf can occur.)
+    return acw > 0.0f && (ax > 0.505f * acw || ay > 0.505f * acw);
 }
 
-__global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug, GBufferPtrs g, unsigned drawW,
+// The loop over the lights for one pixel (lights.comp:141-161): terms added in ascending light order.
+template <bool OPTIMISTIC>
+SZG_DEV V3 lightLoop(const LightRec* __restrict__ lights, unsigned lightCount, const Material& m, bool positionModerate, V3 viewDirection,
+                     bool waveFinite, bool pixelModerate, float& track)
+{
+    V3 sum = splat(0.0f);
+#pragma unroll 1
+    for (unsigned i = 0; i < lightCount; i++)
+    {
+        const LightRec* __restrict__ L = lights + i;
+        LightCull const cur = loadCull(L); // (prefetching light i+1's rows here measured 20 % slower)
+        unsigned const flags = L->leanOK;
+        bool const cullable = waveFinite && (flags & 1u) != 0u;
+        V3 const clip = projectRows(cur, m.position);
+        if (cur.isSpot != 0u && cullable && surelyOutsideCone(clip))
+        {
+            continue;
+        }
+        if (OPTIMISTIC && (flags & 2u) != 0u)
+        {
+            sum = sum + lightContribution<true>(*L, m, positionModerate, viewDirection, cullable, clip, pixelModerate, track);
+        }
+        else
+        {
+            sum = sum + lightContribution<false>(*L, m, positionModerate, viewDirection, cullable, clip, pixelModerate, track);
+        }
+    }
+    return sum;
+}
+
+__global__ __launch_bounds__(256, 6) void k_lights(szg_image color, szg_image debug, GBufferPtrs g, unsigned drawW,
                                                 unsigned localRows, const szg_camera_packed* __restrict__ cameras,
                                                 unsigned cameraIndex, const LightRec* __restrict__ lights, unsigned lightCount)
 {
@@ -506,18 +583,20 @@ __global__ __launch_bounds__(256) void k_lights(szg_image color, szg_image debug
         // wave: when some pixel of the wave has a non-finite factor the whole wave evaluates every light (no term of its
         // sum may be dropped); the flag of the light itself is wave-uniform anyway.
         bool const waveFinite = waveAll(pixelFinite);
-#pragma unroll 1
-        for (unsigned i = 0; i < lightCount; i++)
+        // The optimistic pass (lightContribution<true>): every pixel of the wave finite and within 4096 units of the origin.
+        bool const tightPixel = pixelFinite && fabsf(m.position.x) <= 0x1p12f && fabsf(m.position.y) <= 0x1p12f && fabsf(m.position.z) <= 0x1p12f &&
+                                inRange(fabsf(m.specularPower), 0x1p-100f, 0x1p20f); // (the exponent half of powLeanOK)
+        bool done = false;
+        if (waveAll(tightPixel))
         {
-            const LightRec* __restrict__ L = lights + i;
-            LightCull const cur = loadCull(L); // (prefetching light i+1's rows here measured 20 % slower)
-            bool const cullable = waveFinite && L->leanOK != 0u;
-            V3 const clip = projectRows(cur, m.position);
-            if (cur.isSpot != 0u && cullable && surelyOutsideCone(clip))
-            {
-                continue;
-            }
-            sum = sum + lightContribution(*L, m, positionModerate, viewDirection, cullable, clip, pixelModerate);
+            float track = 0x1p100f;
+            sum = lightLoop<true>(lights, lightCount, m, positionModerate, viewDirection, waveFinite, pixelModerate, track);
+            done = waveAll(track >= 0x1p-30f);
+        }
+        if (!done)
+        {
+            float unused = 0.0f;
+            sum = lightLoop<false>(lights, lightCount, m, positionModerate, viewDirection, waveFinite, pixelModerate, unused);
         }
     }
     row_ptr<uint2>(color, y)[x] = pack_unorm16x4(sum.x, sum.y, sum.z, 1.0f);

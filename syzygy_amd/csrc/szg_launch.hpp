@@ -23,8 +23,11 @@ struct LightRec
     const float* map; // D32F shadow map or nullptr
     unsigned mapWidth, mapHeight;
     unsigned mapPitchFloats;
-    unsigned leanOK; // falloffDistance / falloffFactor / colour*strength of moderate magnitude (lean exact ops allowed)
-    // (leanOK also says: the light's own factors are finite and non-zero where they divide, so a culled pixel's term is an exact 0)
+    unsigned leanOK; // bit 0: falloffDistance / falloffFactor / colour*strength of moderate magnitude (lean exact ops allowed)
+    // (bit 0 also says: the light's own factors are finite and non-zero where they divide, so a culled pixel's term is an exact 0)
+    // bit 1 (implies bit 0), "tight": |position| <= 2^12, |shadow rows| <= 2^14 and falloffBound in [2^-20, 2^20]. Together with
+    // pixel positions <= 2^12 this bounds every operand of the lean ops from ABOVE by construction (|clip| < 2^28, d^2 < 2^28,
+    // falloff < 2^48), so that k_lights' optimistic pass only has to track their LOWER bounds (kernels_deferred.hip).
     float falloffBound;       // falloffFactor / falloffDistance^2 when leanOK: falloffBound * d^2 ~ the light's falloff at distance d
     float rcpFalloffDistance; // rcpN(falloffDistance) when leanOK: the shared reciprocal of dist / falloffDistance (once per light, not per wave)
 };
