@@ -107,6 +107,34 @@ SZG_DEV V3 groundSurfaceTerm(const TLut& L, const Atm& a, V3 origin, V3 directio
 }
 } // namespace
 
+#ifdef SZG_TAIL_DIAG
+// Diagnostic build only (tools/tail_histogram.py; never part of libszg_hip.so): every wave of k_composite stamps the constant-
+// frequency clock (s_memrealtime, 100 MHz) when it starts and when it ends into a buffer the tool hands over, together
+// with the hardware id of where it ran, so that the launch tail can be read off a histogram (profiles/r03_tail_*.txt).
+__device__ unsigned long long* g_tailStamps = nullptr; // [workgroup * 4 + wave] * 3: start, end, HW_ID
+extern "C" int szg_debug_tail_buffer(void* d_buffer)
+{
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_tailStamps), &d_buffer, sizeof d_buffer);
+}
+struct TailStamp
+{
+    unsigned long long start;
+    unsigned slot;
+    SZG_DEV TailStamp(unsigned slot_) : start(wall_clock64()), slot(slot_) {}
+    SZG_DEV ~TailStamp()
+    {
+        if (g_tailStamps != nullptr && (threadIdx.x & 63u) == 0u)
+        {
+            unsigned hw;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+            g_tailStamps[(size_t)slot * 3u + 0u] = start;
+            g_tailStamps[(size_t)slot * 3u + 1u] = wall_clock64();
+            g_tailStamps[(size_t)slot * 3u + 2u] = hw;
+        }
+    }
+};
+#endif
+
 struct GBufferPtrsC
 {
     szg_image diffuse, specular, normal, position, orm;
@@ -141,6 +169,9 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
 {
     unsigned const tid = threadIdx.x;
     unsigned const wave = tid >> 6, lane = tid & 63u;
+#ifdef SZG_TAIL_DIAG
+    TailStamp const stamp((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
+#endif
     unsigned const x = blockIdx.x * 32u + wave * 8u + (lane & 7u);
     // Workgroups are dispatched in blockIdx order; the rows are walked from the bottom of the image upwards so that the
     // cheap workgroups (sky: no march) tend to come last and fill the tail of the launch instead of its start.
