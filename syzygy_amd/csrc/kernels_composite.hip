@@ -172,6 +172,21 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
 #ifdef SZG_TAIL_DIAG
     TailStamp const stamp((blockIdx.y * gridDim.x + blockIdx.x) * 4u + wave);
 #endif
+#ifdef SZG_EXP_LDS_TLUT
+    // EXPERIMENT: stage the first rows of the transmittance LUT (packed rgb) in LDS, once per workgroup
+    __shared__ float s_tlutRows[SZG_EXP_LDS_TLUT * 512 * 3];
+    if (tW == 512)
+    {
+        for (unsigned k = tid; k < (unsigned)(SZG_EXP_LDS_TLUT * 512); k += 256u)
+        {
+            float4 const t = tlut[k];
+            s_tlutRows[k * 3u + 0u] = t.x;
+            s_tlutRows[k * 3u + 1u] = t.y;
+            s_tlutRows[k * 3u + 2u] = t.z;
+        }
+    }
+    __syncthreads();
+#endif
     unsigned const x = blockIdx.x * 32u + wave * 8u + (lane & 7u);
     // Workgroups are dispatched in blockIdx order; the rows are walked from the bottom of the image upwards so that the
     // cheap workgroups (sky: no march) tend to come last and fill the tail of the launch instead of its start.
@@ -183,7 +198,12 @@ __global__ __launch_bounds__(256, 3) void k_composite(szg_image color, szg_image
     unsigned const gy = global_row(rm, y);
 
     Atm const a = load_atm(*prep); // (k_frame_prep: load_atm(atmospheres + atmosphereIndex), once per frame instead of once per wave)
+#ifdef SZG_EXP_LDS_TLUT
+    TLut L = make_tlut(tlut, tW, tH, *prep);
+    L.ldsRows = tW == 512 ? (const __attribute__((address_space(3))) float*)s_tlutRows : nullptr;
+#else
     TLut const L = make_tlut(tlut, tW, tH, *prep);
+#endif
     SkyLut const S{slut, sW, sH, reinterpret_cast<const unsigned*>(slut + (size_t)sW * (size_t)sH)[0] == 0u};
     const szg_camera_packed* cam = cameras + cameraIndex;
 

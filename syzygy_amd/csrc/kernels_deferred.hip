@@ -511,7 +511,7 @@ SZG_DEV bool surelyOutsideCone(V3 clip)
 
 // The loop over the lights for one pixel (lights.comp:141-161): terms added in ascending light order.
 template <bool OPTIMISTIC>
-SZG_DEV V3 lightLoop(const LightRec* __restrict__ lights, unsigned lightCount, const Material& m, bool positionModerate, V3 viewDirection,
+SZG_DEV V3 lightLoop(const LightRec* lights, unsigned lightCount, const Material& m, bool positionModerate, V3 viewDirection,
                      bool waveFinite, bool pixelModerate, float& track)
 {
     V3 sum = splat(0.0f);
@@ -543,6 +543,25 @@ __global__ __launch_bounds__(256, 6) void k_lights(szg_image color, szg_image de
                                                 unsigned localRows, const szg_camera_packed* __restrict__ cameras,
                                                 unsigned cameraIndex, const LightRec* __restrict__ lights, unsigned lightCount)
 {
+#ifdef SZG_EXP_LDS_LIGHTS
+    // EXPERIMENT (profiles/r03_experiments.md, north_star "LDS-staged light lists"; not built into libszg_hip.so): the light
+    // records copied to LDS once per workgroup and read from there (broadcast ds_read into VGPRs) instead of scalar loads
+    // into SGPRs. Up to 264 lights (37 KiB: the 256 spots + the moon of C5).
+    __shared__ LightRec s_lights[264];
+    {
+        unsigned const n = min(lightCount, 264u) * (unsigned)(sizeof(LightRec) / 4u);
+        const unsigned* src = reinterpret_cast<const unsigned*>(lights);
+        unsigned* dst = reinterpret_cast<unsigned*>(s_lights);
+        for (unsigned k = threadIdx.x; k < n; k += 256u)
+        {
+            dst[k] = src[k];
+        }
+        __syncthreads();
+    }
+#define SZG_LIGHTS_PTR s_lights /* (the experiment is run with <= 264 lights) */
+#else
+#define SZG_LIGHTS_PTR lights
+#endif
     unsigned x, y;
     pixel_of_thread_bottom_up(x, y);
     if (x >= drawW || y >= localRows)
@@ -590,13 +609,13 @@ __global__ __launch_bounds__(256, 6) void k_lights(szg_image color, szg_image de
         if (waveAll(tightPixel))
         {
             float track = 0x1p100f;
-            sum = lightLoop<true>(lights, lightCount, m, positionModerate, viewDirection, waveFinite, pixelModerate, track);
+            sum = lightLoop<true>(SZG_LIGHTS_PTR, lightCount, m, positionModerate, viewDirection, waveFinite, pixelModerate, track);
             done = waveAll(track >= 0x1p-30f);
         }
         if (!done)
         {
             float unused = 0.0f;
-            sum = lightLoop<false>(lights, lightCount, m, positionModerate, viewDirection, waveFinite, pixelModerate, unused);
+            sum = lightLoop<false>(SZG_LIGHTS_PTR, lightCount, m, positionModerate, viewDirection, waveFinite, pixelModerate, unused);
         }
     }
     row_ptr<uint2>(color, y)[x] = pack_unorm16x4(sum.x, sum.y, sum.z, 1.0f);

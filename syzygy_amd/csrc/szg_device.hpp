@@ -655,6 +655,12 @@ struct TLut
     // every texel's rgb lies in [2^-50, 2] (status dword behind the texels, szg_launch.hpp "transmittance LUT block"):
     // any bilinear tap then lies in [2^-51, 2.01], inside the operand domain of the lean exact division
     bool moderate;
+#ifdef SZG_EXP_LDS_TLUT
+    // EXPERIMENT (profiles/r03_experiments.md, north_star "LDS-staged ... LUT tiles"; not built into libszg_hip.so): the first
+    // SZG_EXP_LDS_TLUT rows of the LUT as packed rgb in LDS, staged per workgroup by k_composite; taps whose two rows lie
+    // inside (the aerial-perspective marches near the ground: rows 0..3 cover altitudes up to ~90 m) read them with ds_read_b96.
+    const __attribute__((address_space(3))) float* ldsRows;
+#endif
 };
 SZG_DEV bool tlutTexelModerate(float x, float y, float z)
 {
@@ -673,6 +679,9 @@ SZG_DEV TLut make_tlut(const float4* texels, int w, int h)
     t.u_scale = 1.0f - 1.0f / (float)w;
     t.v_bias = 0.5f / (float)h;
     t.v_scale = 1.0f - 1.0f / (float)h;
+#ifdef SZG_EXP_LDS_TLUT
+    t.ldsRows = nullptr;
+#endif
     return t;
 }
 
@@ -739,6 +748,9 @@ SZG_DEV TLut make_tlut(const float4* texels, int w, int h, const FramePrep& f)
     t.u_scale = inVector(f.u_scale);
     t.v_bias = inVector(f.v_bias);
     t.v_scale = inVector(f.v_scale);
+#ifdef SZG_EXP_LDS_TLUT
+    t.ldsRows = nullptr;
+#endif
     return t;
 }
 
@@ -857,10 +869,29 @@ template <bool LEAN = false, bool INNER = false> SZG_DEV V3 sampleT_at(const TLu
         o01 = (p.row1 + (unsigned)i0) << 4;
         o11 = (p.row1 + (unsigned)i1) << 4;
     }
-    Rgb const t00 = *reinterpret_cast<const Rgb*>(base + o00);
-    Rgb const t10 = *reinterpret_cast<const Rgb*>(base + o10);
-    Rgb const t01 = *reinterpret_cast<const Rgb*>(base + o01);
-    Rgb const t11 = *reinterpret_cast<const Rgb*>(base + o11);
+    Rgb t00, t10, t01, t11;
+#ifdef SZG_EXP_LDS_TLUT
+    if (LEAN && INNER && L.ldsRows != nullptr && waveAll(p.row1 < (unsigned)(SZG_EXP_LDS_TLUT * L.width) && p.row0 < (unsigned)(SZG_EXP_LDS_TLUT * L.width)))
+    {
+        // byte offset of texel k in the global LUT is 16 k, in the packed LDS copy 12 k
+        // (explicit LDS address space: through a generic pointer these were flat loads, +84 % on the composite)
+        const __attribute__((address_space(3))) float* const q00 = L.ldsRows + (o00 >> 4) * 3u;
+        const __attribute__((address_space(3))) float* const q10 = L.ldsRows + (o10 >> 4) * 3u;
+        const __attribute__((address_space(3))) float* const q01 = L.ldsRows + (o01 >> 4) * 3u;
+        const __attribute__((address_space(3))) float* const q11 = L.ldsRows + (o11 >> 4) * 3u;
+        t00 = Rgb{q00[0], q00[1], q00[2]};
+        t10 = Rgb{q10[0], q10[1], q10[2]};
+        t01 = Rgb{q01[0], q01[1], q01[2]};
+        t11 = Rgb{q11[0], q11[1], q11[2]};
+    }
+    else
+#endif
+    {
+        t00 = *reinterpret_cast<const Rgb*>(base + o00);
+        t10 = *reinterpret_cast<const Rgb*>(base + o10);
+        t01 = *reinterpret_cast<const Rgb*>(base + o01);
+        t11 = *reinterpret_cast<const Rgb*>(base + o11);
+    }
     float const oma = 1.0f - al;
     float const w00 = oma * p.omb;
     float const w10 = al * p.omb;
