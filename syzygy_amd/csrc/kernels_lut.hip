@@ -157,6 +157,21 @@ __global__ __launch_bounds__(64) void k_frame_prep(const szg_atmosphere_packed* 
     f.u_scale = 1.0f - 1.0f / (float)tW;
     f.v_bias = 0.5f / (float)tH;
     f.v_scale = 1.0f - 1.0f / (float)tH;
+    {
+        // TLut::rowsInterior: radiusPart's v coordinate (same expressions, same contraction classes) at x_radius = 0 - every
+        // radius at or below the planet's - and at the largest radius an INNER march can hand it, with a margin of 2^-16
+        // for the few ulps by which a geometric length may exceed the analytic bound
+        auto vOf = [&](float x_radius) {
+            float const t = SZG_CON(SZG_C_LUTMAP, x_radius, f.v_scale, f.v_bias);
+            return SZG_CON(SZG_C_TEXCOORD, t, f.fheight, -0.5f);
+        };
+        float const rMax = sqrtf(f.a.innerCeil2) * (1.0f + 0x1p-16f);
+        float const rhoMax = safeSqrt(rMax * rMax - f.a.Rp2);
+        float const vLo = vOf(0.0f), vHi = vOf(rhoMax / f.a.H);
+        bool const ok = f.a.lean && vLo >= 0.0f && floorf(vHi) + 1.0f <= f.fheight - 1.0f && vHi == vHi && tW >= 2 && tH >= 2 &&
+                        (float)tW * (float)tH <= 0x1p24f;
+        f.rowsInterior = ok ? 1u : 0u;
+    }
 #pragma unroll
     for (int k = 0; k < 16; k++)
     {

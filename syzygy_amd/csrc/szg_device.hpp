@@ -655,6 +655,10 @@ struct TLut
     // every texel's rgb lies in [2^-50, 2] (status dword behind the texels, szg_launch.hpp "transmittance LUT block"):
     // any bilinear tap then lies in [2^-51, 2.01], inside the operand domain of the lean exact division
     bool moderate;
+    // wave-uniform, from k_frame_prep (FramePrep::rowsInterior): for every radius of an INNER march (radius^2 <= Atm::innerCeil2,
+    // with a margin of 2^-16) both LUT rows of a tap, floor(v) and floor(v) + 1, lie inside [0, H - 1] - the two clamps of
+    // radiusPart are identities there and the row offsets can be formed in float
+    bool rowsInterior;
 #ifdef SZG_EXP_LDS_TLUT
     // EXPERIMENT (profiles/r03_experiments.md, north_star "LDS-staged ... LUT tiles"; not built into libszg_hip.so): the first
     // SZG_EXP_LDS_TLUT rows of the LUT as packed rgb in LDS, staged per workgroup by k_composite; taps whose two rows lie
@@ -679,6 +683,7 @@ SZG_DEV TLut make_tlut(const float4* texels, int w, int h)
     t.u_scale = 1.0f - 1.0f / (float)w;
     t.v_bias = 0.5f / (float)h;
     t.v_scale = 1.0f - 1.0f / (float)h;
+    t.rowsInterior = false;
 #ifdef SZG_EXP_LDS_TLUT
     t.ldsRows = nullptr;
 #endif
@@ -696,6 +701,9 @@ struct FramePrep
     // products that are the same for every pixel (round 2 formed them per lane, ~300 VALU instructions per geometry pixel when a
     // sun shadow map is bound). Same mul(), same order; read back through scalar loads. Valid when the composite has a sun map.
     float sunShadow[16];
+    // TLut::rowsInterior (k_frame_prep evaluates the LUT's v coordinate at both ends of the INNER radius range: the map is
+    // monotone, every operation in it being correctly rounded)
+    unsigned rowsInterior;
 };
 // The block arrives through scalar loads; its floats then move to vector registers, where the per-wave derivation used to
 // leave them: a VALU instruction of gfx950 reads at most one scalar operand, and ~70 constants held in scalar registers
@@ -748,6 +756,7 @@ SZG_DEV TLut make_tlut(const float4* texels, int w, int h, const FramePrep& f)
     t.u_scale = inVector(f.u_scale);
     t.v_bias = inVector(f.v_bias);
     t.v_scale = inVector(f.v_scale);
+    t.rowsInterior = f.rowsInterior != 0u;
 #ifdef SZG_EXP_LDS_TLUT
     t.ldsRows = nullptr;
 #endif
@@ -800,7 +809,7 @@ struct RadiusPart
     unsigned row1;      // SGPR-base + VGPR-offset addressing instead of 64-bit VALU address arithmetic
     float b, omb;       // v weight and 1 - b
 };
-template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const Atm& a, float radius)
+template <bool LEAN = false, bool INNER = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const Atm& a, float radius)
 {
     RadiusPart p;
     p.r = radius;
@@ -820,6 +829,16 @@ template <bool LEAN = false> SZG_DEV RadiusPart radiusPart(const TLut& L, const 
     // instead of two integer ones per index): the same indices for every finite fv (integer-valued; beyond 2^24
     // fv + 1 == fv and both land on the same edge, as the saturating conversion does). For a NaN fv the weights are NaN
     // and so is the result, whichever texels are fetched.
+    if (LEAN && INNER && L.rowsInterior)
+    {
+        // 0 <= fv <= H - 2 for every radius of this march (TLut::rowsInterior): the clamped indices are fv and fv + 1 themselves,
+        // and fv * W is an exact float product below 2^24 (the flag also says W * H <= 2^24): one conversion, one full-rate
+        // multiply and one add instead of two clamps, two conversions and two integer multiplies. (A NaN fv converts to row 0
+        // and has NaN weights: a NaN tap whichever texels are fetched, as above.)
+        p.row0 = (unsigned)(int)(fv * L.fwidth);
+        p.row1 = p.row0 + (unsigned)L.width;
+        return p;
+    }
     float const hm1 = L.fheight - 1.0f;
     int const j0 = (int)__builtin_amdgcn_fmed3f(fv, 0.0f, hm1);
     int const j1 = (int)__builtin_amdgcn_fmed3f(fv + 1.0f, 0.0f, hm1);
@@ -1024,7 +1043,7 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
     // so its length and radius part are carried from one iteration to the next.
     V3 begin = fnma(0.0f * m.dS, m.scatteringDir, m.origin);
     float lenBegin = sqrtPX<LEAN>(dotA(begin, begin));
-    RadiusPart pBegin = radiusPart<LEAN>(L, a, lenBegin);
+    RadiusPart pBegin = radiusPart<LEAN, INNER>(L, a, lenBegin);
 #pragma unroll 1
     for (unsigned i = 0; i < 32u; i++)
     {
@@ -1032,7 +1051,7 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
         float const t = fi * m.dS;
         V3 const end = fnma((float)(i + 1u) * m.dS, m.scatteringDir, m.origin);
         float const lenEnd = sqrtPX<LEAN>(dotA(end, end));
-        RadiusPart const pEnd = radiusPart<LEAN>(L, a, lenEnd);
+        RadiusPart const pEnd = radiusPart<LEAN, INNER>(L, a, lenEnd);
 
         // stepRadiusMu(originStep, t), common.glinl:329-331
         // (on a lean path this is a squared radius above the lean floor: neither the clamp to 0 nor sqrtN's guard is needed)
@@ -1041,7 +1060,7 @@ template <bool LEAN, bool INNER = false> SZG_DEV V3 marchLoop(const TLut& L, con
         float const yS = LEAN ? rcpN(s_radius) : 0.0f;
         float const s_mu = divRX<LEAN>(m.r_mu + t, s_radius, yS);
         float const s_musun = divRX<LEAN>(SZG_CON(SZG_C_STEP, t, m.mu_sunAndStep, m.r_musun), s_radius, yS);
-        RadiusPart const pStep = radiusPart<LEAN>(L, a, s_radius);
+        RadiusPart const pStep = radiusPart<LEAN, INNER>(L, a, s_radius);
 
         float const altitude = lenBegin - a.planetRadius;
 
