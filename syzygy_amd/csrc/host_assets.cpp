@@ -1407,6 +1407,13 @@ class Loader
         loadViewsAndAccessors();
         loadMaterials();
         loadMeshes();
+        if (jpegRefused_ > 0)
+        {
+            // (not a line the reference prints: it decodes JPEG through stb_image. Asset IO is outside the hot path and frozen; the
+            // summary is there so that a caller notices why materials came out with the default maps.)
+            warn("Summary: " + std::to_string(jpegRefused_) + " image(s) of this asset are JPEG streams, which this build does not decode (PNG only); "
+                 "the materials that reference them use the default maps.");
+        }
         return SZG_OK;
     }
 
@@ -1429,6 +1436,7 @@ class Loader
         Bytes rgba;
     };
     std::vector<DecodedImage> images_;
+    int jpegRefused_ = 0; // images refused because they are JPEG streams (decodeImageBytes), for the summary warning
 
     void warn(const std::string& line)
     {
@@ -1679,6 +1687,7 @@ class Loader
         {
             warn("stbi: Failed to convert image. (" + what + ": " + why + ")");
             warn("Failed to load image from glTF.");
+            jpegRefused_ += (bytes.size() >= 2 && bytes[0] == 0xFF && bytes[1] == 0xD8) ? 1 : 0;
             return false;
         }
         d.ok = true;

@@ -405,6 +405,7 @@ def test_gltf_material_maps_and_channel_overrides(tmp_path):
     assert "Material bare: Missing color texture." in text and "Material bare: Missing metallicRoughness texture" in text
     assert "does not result in a valid file path. URI was: nowhere.png" in text
     assert "stbi: Failed to convert image." in text
+    assert "Summary: 1 image(s) of this asset are JPEG streams" in text  # so that a caller notices the PNG-only limitation
     assert "was missing imageIndex" in text and "Out of bounds texture index." not in text  # index 6 exists but has no source
     for kind in ("ORM", "color", "normal"):
         assert f"Material broken: Failed to upload {kind} texture." in text
