@@ -341,14 +341,13 @@ SZG_DEV float sqrtU(bool lean, float x) { return lean ? sqrtN(x) : sqrtf(x); }
 // the loop and repeats the wave's loop with the tested form if it ever fell below the threshold.
 template <bool OPTIMISTIC>
 SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool positionModerate, V3 viewDirection, bool cullable, V3 clip,
-                             bool backCull, float& track)
+                             bool backCull, float d2, float& track)
 {
     const float* R = L.shadowRows;
     float const cx = clip.x, cy = clip.y, cw = clip.z;
     bool const isSpot = L.isSpot != 0u;
     V3 const lightDir = mk3(L.dir[0], L.dir[1], L.dir[2]);
-    V3 const toLight = mk3(L.position[0], L.position[1], L.position[2]) - m.position;
-    float const d2 = dotL(toLight, toLight);
+    // (d2 = dot(toLight, toLight) of distance(), lights.comp:80, formed by the caller in front of the cone test)
     // The surface faces away from the light: clamp(dot(N, L), 0, 1) = 0 (also for a NaN, fmax(NaN, 0) = 0) is the last factor
     // of ((occlusion * brdf) * spectral) * clamp(N.L) (lights.comp:106-107), so the term is +-0 - and sum + (+-0) == sum, the sum
     // being never -0 - provided the other factors are finite numbers whose product does not overflow:
@@ -407,7 +406,8 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
         // cull needs no square root. x / 0.5 == x * 2 exactly.
         float const ddx = sx - 0.5f, ddy = sy - 0.5f;
         float const q = SZG_CON(SZG_C_LDOT, ddy, ddy, ddx * ddx); // dot(d, d) of distance()
-        if (q >= 0.25f && cullable)
+        // (an exact zero only while colour * strength / falloff is finite: see falloffAwayFromZero in lightLoop)
+        if (q >= 0.25f && cullable && L.falloffBound * d2 >= 0x1p-28f)
         {
             return splat(0.0f);
         }
@@ -473,6 +473,7 @@ SZG_DEV V3 lightContribution(const LightRec& L, const Material& m, bool position
 struct LightCull
 {
     float rx[4], ry[4], rw[4];
+    float position[3], falloffBound;
     unsigned isSpot;
 };
 SZG_DEV LightCull loadCull(const LightRec* __restrict__ L)
@@ -485,6 +486,10 @@ SZG_DEV LightCull loadCull(const LightRec* __restrict__ L)
         c.ry[k] = L->shadowRows[4 + k];
         c.rw[k] = L->shadowRows[12 + k];
     }
+    c.position[0] = L->position[0];
+    c.position[1] = L->position[1];
+    c.position[2] = L->position[2];
+    c.falloffBound = L->falloffBound;
     c.isSpot = L->isSpot;
     return c;
 }
@@ -523,17 +528,26 @@ SZG_DEV V3 lightLoop(const LightRec* lights, unsigned lightCount, const Material
         unsigned const flags = L->leanOK;
         bool const cullable = waveFinite && (flags & 1u) != 0u;
         V3 const clip = projectRows(cur, m.position);
-        if (cur.isSpot != 0u && cullable && surelyOutsideCone(clip))
+        // A pixel outside the cone contributes (colour * strength / falloff) * 0 * ...: an exact zero ONLY while the quotient
+        // is finite. The falloff factor * (distance / falloffDistance)^2 is 0 AT the light's position and underflows next to
+        // it, and inf * 0 = NaN poisons the pixel in the reference (found in round 3 by a test that puts G-buffer positions
+        // on the lights: rounds 1 and 2 returned 0 there). So the squared distance is formed in front of the cone test, and
+        // the two cone culls - like the back-face cull - require falloffBound * d^2 >= 2^-28 (falloff >= 2^-30 with a factor of
+        // 4 for the roundings): closer pixels are evaluated in full.
+        V3 const toLight = mk3(cur.position[0], cur.position[1], cur.position[2]) - m.position;
+        float const d2 = dotL(toLight, toLight);
+        bool const falloffAwayFromZero = cur.falloffBound * d2 >= 0x1p-28f;
+        if (cur.isSpot != 0u && cullable && falloffAwayFromZero && surelyOutsideCone(clip))
         {
             continue;
         }
         if (OPTIMISTIC && (flags & 2u) != 0u)
         {
-            sum = sum + lightContribution<true>(*L, m, positionModerate, viewDirection, cullable, clip, pixelModerate, track);
+            sum = sum + lightContribution<true>(*L, m, positionModerate, viewDirection, cullable, clip, pixelModerate, d2, track);
         }
         else
         {
-            sum = sum + lightContribution<false>(*L, m, positionModerate, viewDirection, cullable, clip, pixelModerate, track);
+            sum = sum + lightContribution<false>(*L, m, positionModerate, viewDirection, cullable, clip, pixelModerate, d2, track);
         }
     }
     return sum;

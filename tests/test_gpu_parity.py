@@ -213,6 +213,33 @@ def test_lights_nan_gbuffer_poisons_culled_lights_too(gpu):
     assert (got_q == frame.color).all()
 
 
+def test_lights_optimistic_pass_falls_back_when_an_operand_leaves_the_lean_domain(gpu):
+    """k_lights runs its light loop optimistically (lean exact operators without per-pair range tests, the operands' lower
+    bounds folded into a running minimum) and repeats a wave's loop with the tested form when the minimum says an operand left
+    the domain. Force that: pixels whose world position IS a spot light's position (distance 0: falloff 0, colour / 0 = inf,
+    inf * 0 = NaN further on) and pixels a hair away from it (d^2 far below 2^-30). The image, including its inf / NaN pattern,
+    must still be the oracle's bit for bit."""
+    inp = util.Inputs(160, 90, elevation_degrees=70.0, spots=24)
+    positions = [tuple(inp.spots[i].position[:3]) for i in range(24)]
+
+    def poison(frame):
+        geometry = np.argwhere(frame.depth > 0)
+        rng = np.random.default_rng(11)
+        picks = geometry[rng.choice(len(geometry), 48, replace=False)]
+        for k, (y, x) in enumerate(picks):
+            p = np.array(positions[k % 24], np.float32)
+            if k >= 24:
+                p = p + np.float32(1e-7) * np.array([1.0, -2.0, 0.5], np.float32)
+            frame.position[y, x, :3] = p
+
+    got, got_q, frame = run_lights_case(gpu, 160, 90, 24, 2, poison=poison)
+    assert not np.isfinite(frame.debug).all()  # the case does produce inf / NaN pixels in the reference's arithmetic
+    assert (np.isnan(got) == np.isnan(frame.debug)).all()
+    ok = ~np.isnan(got)
+    assert (got.view(np.uint32)[ok] == frame.debug.view(np.uint32)[ok]).all()
+    assert (got_q == frame.color).all()
+
+
 def test_lights_ragged_extent(gpu):
     got, got_q, frame = run_lights_case(gpu, 70, 37, 8, 1)
     assert_close(got, frame.debug, what="lights 70x37")
