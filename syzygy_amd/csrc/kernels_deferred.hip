@@ -289,6 +289,16 @@ __global__ void k_light_prep(const szg_directional_light_packed* __restrict__ di
     }
     r.rcpFalloffDistance = r.leanOK != 0u ? rcpN(r.falloffDistance) : 0.0f;
     r.falloffBound = r.falloffFactor * r.rcpFalloffDistance * r.rcpFalloffDistance;
+    // The falloff of a lean pair is falloffBound * d^2 up to rounding, with d^2 in [2^-30, 2^30] (tested per pair): it is the
+    // denominator of colour * strength / falloff, so it has to stay inside the domain of the exact reciprocal, [2^-60, 2^60]
+    // (round 3: factor and distance were only bounded one by one before, which admitted falloffs up to 2^120 and quotients in
+    // the denormal range, where the one-correction division is not the IEEE quotient).
+    if (r.leanOK != 0u && !inRange(r.falloffBound, 0x1p-30f, 0x1p30f))
+    {
+        r.leanOK = 0u;
+        r.rcpFalloffDistance = 0.0f;
+        r.falloffBound = 0.0f;
+    }
     if (r.leanOK != 0u)
     {
         bool tight = fabsf(r.position[0]) <= 0x1p12f && fabsf(r.position[1]) <= 0x1p12f && fabsf(r.position[2]) <= 0x1p12f &&

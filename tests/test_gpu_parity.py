@@ -152,8 +152,10 @@ def test_gbuffer_fill_bit_exact(gpu, size):
 # ---------------------------------------------------------------------------
 # lights pass
 # ---------------------------------------------------------------------------
-def run_lights_case(gpu, W, H, spots, skip, elevation=70.0, shadow=None, tile=None, poison=None):
+def run_lights_case(gpu, W, H, spots, skip, elevation=70.0, shadow=None, tile=None, poison=None, mutate=None):
     inp = util.Inputs(W, H, elevation_degrees=elevation, spots=spots)
+    if mutate is not None:
+        mutate(inp)
     cameras, atmospheres, lights = staged(gpu, inp)
     rows = H if tile is None else tile.local_rows
     frame = gpu.ob.HostFrame(W, rows)
@@ -238,6 +240,29 @@ def test_lights_optimistic_pass_falls_back_when_an_operand_leaves_the_lean_domai
     ok = ~np.isnan(got)
     assert (got.view(np.uint32)[ok] == frame.debug.view(np.uint32)[ok]).all()
     assert (got_q == frame.color).all()
+
+
+def test_lights_with_extreme_falloff_parameters(gpu):
+    """Spot lights whose falloff factor and distance are each of 'moderate' magnitude but whose combination is not:
+    factor * (d / distance)^2 up to 2^80 and down to 2^-80, colour * strength down to 2^-29 - quotients at the edge of the
+    normal range and below it. Such lights must leave the lean exact operators' domain (k_light_prep) and come out
+    bit-identical to the oracle's IEEE divisions, denormals included."""
+    def mutate(inp):
+        settings = [(2.0 ** 25, 2.0 ** -25, 1.0), (2.0 ** -25, 2.0 ** 25, 1.0), (2.0 ** 29, 2.0 ** -20, 2.0 ** -29),
+                    (2.0 ** -29, 2.0 ** 29, 2.0 ** 29), (1.0, 2.0 ** -29, 2.0 ** -20), (2.0 ** 20, 1.0, 2.0 ** -29)]
+        for i, (factor, distance, strength) in enumerate(settings):
+            for k in (i, i + 6):
+                inp.spots[k].falloffFactor = factor
+                inp.spots[k].falloffDistance = distance
+                inp.spots[k].strength = strength
+
+    got, got_q, frame = run_lights_case(gpu, 160, 90, 12, 2, mutate=mutate)
+    assert np.isfinite(frame.debug).all()
+    assert (got.view(np.uint32) == frame.debug.view(np.uint32)).all()
+    assert (got_q == frame.color).all()
+    values = np.abs(frame.debug[..., :3])
+    print("extreme falloff: smallest non-zero pixel value", values[values > 0].min(), "largest", values.max())
+    assert (values > 0).any()
 
 
 def test_lights_ragged_extent(gpu):
