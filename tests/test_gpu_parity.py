@@ -223,15 +223,23 @@ def test_lights_optimistic_pass_falls_back_when_an_operand_leaves_the_lean_domai
     must still be the oracle's bit for bit."""
     inp = util.Inputs(160, 90, elevation_degrees=70.0, spots=24)
     positions = [tuple(inp.spots[i].position[:3]) for i in range(24)]
+    forwards = [np.array(inp.spots[i].forward[:3], np.float64) for i in range(24)]
+    camera = np.array(inp.cam.position[:3], np.float64)
 
     def poison(frame):
         geometry = np.argwhere(frame.depth > 0)
         rng = np.random.default_rng(11)
-        picks = geometry[rng.choice(len(geometry), 48, replace=False)]
+        picks = geometry[rng.choice(len(geometry), 72, replace=False)]
         for k, (y, x) in enumerate(picks):
-            p = np.array(positions[k % 24], np.float32)
-            if k >= 24:
-                p = p + np.float32(1e-7) * np.array([1.0, -2.0, 0.5], np.float32)
+            if k < 48:
+                p = np.array(positions[k % 24], np.float32)
+                if k >= 24:
+                    p = p + np.float32(1e-7) * np.array([1.0, -2.0, 0.5], np.float32)
+            else:
+                # ... and pixels seen exactly against a light's direction: view direction = -light direction, so the half
+                # vector light + view has a squared length of ~1e-14 (below the 2^-40 the lean normalisation needs) or 0
+                light_dir = -forwards[k % 24] / np.linalg.norm(forwards[k % 24])
+                p = (camera + light_dir * (3.0 + 0.37 * (k - 48))).astype(np.float32)
             frame.position[y, x, :3] = p
 
     got, got_q, frame = run_lights_case(gpu, 160, 90, 24, 2, poison=poison)
