@@ -333,12 +333,15 @@ def test_lights_linearity(gpu):
 # ---------------------------------------------------------------------------
 # composite on identical LUTs / G-buffer / prior colour
 # ---------------------------------------------------------------------------
-def run_composite_case(gpu, W, H, elevation, spots=8, sun_shadow=None, tile=None, camera=None, lut=((512, 128), (256, 128))):
+def run_composite_case(gpu, W, H, elevation, spots=8, sun_shadow=None, tile=None, camera=None, lut=((512, 128), (256, 128)),
+                       poison=None):
     inp = util.Inputs(W, H, elevation_degrees=elevation, spots=spots, camera=camera)
     cameras, atmospheres, lights = staged(gpu, inp)
     rows = H if tile is None else tile.local_rows
     frame = gpu.ob.HostFrame(W, rows)
     gpu.ob.gbuffer_fill(frame, inp.rect, tile, inp.cam, inp.synthetic.fill, threads=8)
+    if poison is not None:
+        poison(frame, inp)
     gpu.ob.lights(frame, inp.rect, tile, None, inp.cam, inp.dirs, 2, 1, inp.spots, spots, threads=8)
     prior = frame.color.copy()
     (tw, th), (sw, sh) = lut
@@ -391,6 +394,43 @@ def test_composite_with_sun_shadow_map(gpu):
     shadow = rng.random((96, 96), dtype=np.float32)
     got, got_q, frame = run_composite_case(gpu, 160, 90, 40.0, sun_shadow=shadow)
     assert_close(got, frame.debug, what="composite with sun shadow map")
+
+
+@pytest.mark.parametrize("elevation", [35.0, 2.0])
+def test_composite_structured_coincidences(gpu, elevation):
+    """Coincidences a random sweep never draws (round 3 found the lights pass wrong for a pixel AT a light's position this way):
+    G-buffer positions exactly on the camera and one ulp beside it (zero-length view segment, NaN direction of
+    sampleTransmittanceLUT_Segment), exactly at ground level and at the sub-camera point, far outside the atmosphere, metal
+    pixels whose normal is the view direction, its negation, or the zero vector, and normals that make the reflection
+    exactly horizontal. The image, with its NaN pattern, must be the oracle's bit for bit."""
+    def poison(frame, inp):
+        cam = np.array(inp.cam.position[:3], np.float32)
+        geometry = np.argwhere(frame.depth > 0)
+        rng = np.random.default_rng(23)
+        picks = geometry[rng.choice(len(geometry), 120, replace=False)]
+        up = np.float32(np.nextafter(np.float32(cam[1]), np.float32(1e9)))
+        cases = [cam, np.array([cam[0], up, cam[2]], np.float32), np.array([np.nextafter(cam[0], np.float32(9e9)), cam[1], cam[2]], np.float32),
+                 np.array([cam[0], 0.0, cam[2]], np.float32), np.array([3.0, 0.0, -2.0], np.float32), np.array([cam[0], -1e-30, cam[2]], np.float32),
+                 np.array([2.0e8, -1.0e8, 5.0e7], np.float32), np.array([0.0, -1.2e5, 0.0], np.float32)]
+        for k, (y, x) in enumerate(picks):
+            c = k % 12
+            if c < len(cases):
+                frame.position[y, x, :3] = cases[c]
+            else:
+                view = cam - frame.position[y, x, :3]
+                n = np.linalg.norm(view)
+                view = view / n if n > 0 else view
+                normal = {8: view, 9: -view, 10: np.zeros(3, np.float32), 11: np.array([0.0, -1.0, 0.0], np.float32)}[c]
+                frame.normal[y, x, :3] = normal.astype(np.float16)
+                frame.orm[y, x, 2] = np.float16(1.0)  # metallic: the reflection branch is taken
+            if k % 3 == 0:
+                frame.orm[y, x, 2] = np.float16(1.0)
+
+    got, got_q, frame = run_composite_case(gpu, 160, 90, elevation, poison=poison)
+    assert (np.isnan(got) == np.isnan(frame.debug)).all()
+    ok = ~np.isnan(got)
+    assert (got.view(np.uint32)[ok] == frame.debug.view(np.uint32)[ok]).all()
+    assert (got_q == frame.color).all()
 
 
 def test_composite_camera_looking_down_and_up(gpu):
