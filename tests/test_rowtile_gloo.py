@@ -65,7 +65,8 @@ def _worker(rank, world, port, block_rows, out_path, W, H):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,block_rows,size", [(2, 8, (48, 40)), (3, 4, (40, 30)), (2, 16, (32, 20))])
+# (8 ranks: the configuration north_star names; 17 blocks of 8 rows, so the shares are unequal - 3, 2, 2, ... blocks)
+@pytest.mark.parametrize("world,block_rows,size", [(2, 8, (48, 40)), (3, 4, (40, 30)), (2, 16, (32, 20)), (8, 8, (40, 136))])
 def test_rowtile_gather_compose_gloo(world, block_rows, size):
     W, H = size
     with tempfile.TemporaryDirectory() as tmp:
@@ -96,7 +97,7 @@ def _lut_worker(rank, world, port, out_path):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("world", [2, 4, 8])
 def test_lut_slices_allgather_gloo(world):
     with tempfile.TemporaryDirectory() as tmp:
         out_path = os.path.join(tmp, "r")
