@@ -100,11 +100,18 @@ def test_replicas_line_of_the_batch_workload_through_the_self_launcher():
 
 def test_bench_roofline_names_the_dominant_kernel_of_each_workload():
     """`roofline` describes the longest pass of the run it belongs to, and takes `traffic` only from the committed counter
-    profile of the same workload and kernel (profiles/r02_pmc_<workload>.json)."""
+    profile of the same workload and kernel (the latest profiles/rNN_pmc_<workload>.json), and says which tree that profile
+    was collected from."""
     c5 = _run([sys.executable, "bench.py", "--workload", "c5", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
     assert c5["roofline"]["kernel"] == "k_lights" and c5["roofline"]["avg_launch_ms"] == pytest.approx(c5["pass_ms_rank0"]["lights"])
     assert c5["roofline"]["algorithmic_bytes_per_launch"] == 56 * 3840 * 2160
-    assert c5["roofline"]["traffic"] is not None and c5["roofline"]["traffic_source"].endswith("r02_pmc_c5.json")
+    import glob
+    import re
+
+    latest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_c5.json")))[-1]
+    assert c5["roofline"]["traffic"] is not None and c5["roofline"]["traffic_source"] == os.path.relpath(latest, ROOT)
+    assert re.fullmatch(r"[0-9a-f]{16}", c5["roofline"]["traffic_profile"]["source_hash"] or "") or "r02_" in latest
+    assert re.fullmatch(r"[0-9a-f]{16} contract=0x[0-9a-f]{4}", c5["library_build_id"])
     c3 = _run([sys.executable, "bench.py", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-extras"])
     assert c3["roofline"]["kernel"] == "k_composite" and c3["roofline_valu"]["kernel"] == "k_composite"
     assert 0.5 < c3["roofline_valu"]["frac_of_issue_ceiling_at_2.4GHz"] < 1.0
