@@ -64,7 +64,7 @@ template <typename F> bool bind(void* handle, const char* name, F& out, bool req
     return true;
 }
 
-// An RCCL that is already mapped into this process (any object whose file name starts with "librccl"): its path, or "".
+// An RCCL that is already mapped into this process (an object whose file name starts with "librccl.so"): its path, or "".
 int find_mapped_rccl(struct dl_phdr_info* info, size_t, void* out)
 {
     const char* const path = info->dlpi_name;
@@ -74,7 +74,7 @@ int find_mapped_rccl(struct dl_phdr_info* info, size_t, void* out)
     }
     const char* const slash = strrchr(path, '/');
     const char* const base = slash != nullptr ? slash + 1 : path;
-    if (strncmp(base, "librccl", 7) == 0)
+    if (strncmp(base, "librccl.so", 10) == 0) // librccl.so, librccl.so.1, librccl.so.1.0.x - not librccl-net.so and the like
     {
         snprintf(static_cast<char*>(out), 400, "%s", path);
         return 1;
