@@ -287,24 +287,41 @@ int szg_rowtile_comm_create_deadline(szg_rowtile_comm_t** out, int rank, int nra
         ncclComm_t lut = nullptr, tiles = nullptr;
         ncclUniqueId ids[2];
     };
-    auto st = std::make_shared<Init>();
+    // (nothing may throw across the C boundary: allocation of the shared state and creation of the thread are guarded)
+    std::shared_ptr<Init> st;
+    std::thread worker;
+    try
+    {
+        st = std::make_shared<Init>();
+    }
+    catch (...)
+    {
+        return fail(SZG_ERR_OUT_OF_MEMORY, "szg_rowtile_comm_create: host allocation failed");
+    }
     std::memcpy(st->ids, unique_id, sizeof st->ids);
     const Rccl* const rp = &r;
-    std::thread worker([st, rp, rank, nranks, device] {
-        ncclResult_t e = ncclUnhandledCudaError;
-        if (hipSetDevice(device) == hipSuccess)
-        {
-            e = rp->CommInitRank(&st->lut, nranks, st->ids[0], rank);
-            if (e == ncclSuccess)
+    try
+    {
+        worker = std::thread([st, rp, rank, nranks, device] {
+            ncclResult_t e = ncclUnhandledCudaError;
+            if (hipSetDevice(device) == hipSuccess)
             {
-                e = rp->CommInitRank(&st->tiles, nranks, st->ids[1], rank);
+                e = rp->CommInitRank(&st->lut, nranks, st->ids[0], rank);
+                if (e == ncclSuccess)
+                {
+                    e = rp->CommInitRank(&st->tiles, nranks, st->ids[1], rank);
+                }
             }
-        }
-        std::lock_guard<std::mutex> lock(st->m);
-        st->result = e;
-        st->done = true;
-        st->cv.notify_all();
-    });
+            std::lock_guard<std::mutex> lock(st->m);
+            st->result = e;
+            st->done = true;
+            st->cv.notify_all();
+        });
+    }
+    catch (...)
+    {
+        return fail(SZG_ERR_HIP, "szg_rowtile_comm_create: the helper thread of the rendezvous could not be started");
+    }
     bool finished;
     {
         std::unique_lock<std::mutex> lock(st->m);
