@@ -101,6 +101,36 @@ def test_skyview_lut_reference_size_band(gpu):
     sky.destroy()
 
 
+@pytest.mark.parametrize("elevation", [35.0, 0.0, 90.0])
+def test_luts_at_structured_camera_altitudes(gpu, elevation):
+    """Coincidences a random camera never hits: the camera exactly ON the ground (radius == planet radius: the horizon angle is
+    asin(1)), one ulp above and below it, exactly at the top of the atmosphere and just outside it, deep underground - with
+    the sun at 35 degrees, exactly on the horizon and exactly at the zenith (the undefined azimuth of SURVEY Q15). Sky-view LUT
+    on the GPU's own transmittance LUT against the oracle chain, bit for bit including the NaN pattern."""
+    from syzygy_amd import scene
+
+    shell_m = 100000.0  # scene.cpp:52-75: atmosphere radius - planet radius = 0.1 Mm
+    for y in (0.0, -np.float32(1e-45), np.float32(1e-45), -0.5, -shell_m, -np.nextafter(np.float32(shell_m), np.float32(2e5)),
+              -np.nextafter(np.float32(shell_m), np.float32(0.0)), 250.0, -2.0e5):
+        cam = scene.default_camera()
+        cam.cameraPosition[:] = [0.0, float(y), 0.0]
+        inp = util.Inputs(64, 64, elevation_degrees=elevation, camera=cam)
+        cameras, atmospheres, lights = staged(gpu, inp)
+        sky = gpu.pl.SkyViewComputePipeline.create(transmittance_extent=(256, 64), skyview_extent=(128, 64))
+        sky.recordTransmittance(None, 0, atmospheres)
+        sky.recordSkyViewLUT(None, 0, atmospheres, 0, cameras)
+        torch.cuda.synchronize()
+        got_t = sky.download_lut(sky.transmittanceLUT())
+        got_s = sky.download_lut(sky.skyviewLUT())
+        want_t = gpu.ob.transmittance_lut(inp.atm, 256, 64, threads=8)
+        want_s = gpu.ob.skyview_lut(inp.atm, inp.cam, want_t, 128, 64, threads=8)
+        assert (got_t.view(np.uint32) == want_t.view(np.uint32)).all(), y
+        assert (np.isnan(got_s) == np.isnan(want_s)).all(), y
+        ok = ~np.isnan(got_s)
+        assert (got_s.view(np.uint32)[ok] == want_s.view(np.uint32)[ok]).all(), y
+        sky.destroy()
+
+
 def test_skyview_lut_row_slices_equal_the_full_lut(gpu):
     """Multi-GPU extension: N row slices (szg_skyview_record_skyview_lut_rows) == the whole LUT, bit for bit;
     the LUT memory aliased as a torch tensor is the same storage."""
